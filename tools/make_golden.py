@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the hot path from the reference's OWN functions.
+
+Runs only in the build container (needs /root/reference).  Nothing of the
+reference is copied into this repository: the reference module is read at run
+time, converted py2->py3 with the stdlib's lib2to3 in a scratch directory
+outside the repo, and only the hot-path FunctionDefs are exec'd (the module as
+a whole cannot be imported: py2 syntax at frisk/__init__.py:95, and top-level
+imports of hmmlearn / pybedtools / seaborn which are absent - SURVEY.md §8c).
+
+Outputs (committed, data only):
+  tests/golden/<case>.json   rows, scalars (floats round-trip through repr)
+  tests/golden/<case>.npz    integer count tables (genome profile, per-window)
+
+Driver = the reference's own call pattern: phase A is the call at
+frisk/__init__.py:1442, phase B the loop at frisk/__init__.py:1478-1494.
+"""
+import argparse
+import ast
+import copy
+import gzip
+import itertools
+import json
+import logging
+import math
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+import tempfile
+from collections import Counter
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, ".."))
+GOLD = os.path.join(REPO, "tests", "golden")
+INP = os.path.join(GOLD, "inputs")
+REF_SRC = "/root/reference/frisk/__init__.py"
+
+HOT_FUNCS = ["countN", "calcGC", "iterFasta", "crawlGenome", "prepareMaps", "rangeMaps",
+             "revComplement", "computeKmers", "IvomBuild", "KLD", "calcRIP", "makePicklePath"]
+
+
+def load_reference_functions():
+    scratch = tempfile.mkdtemp(prefix="frisk_oracle_")
+    dst = os.path.join(scratch, "frisk_py2.py")
+    shutil.copy(REF_SRC, dst)
+    subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n", dst], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tree = ast.parse(open(dst).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in HOT_FUNCS]
+    assert sorted(n.name for n in keep) == sorted(HOT_FUNCS), [n.name for n in keep]
+    mod = ast.Module(body=keep, type_ignores=[])
+
+    class _NP:  # calcRIP uses np.NaN (removed in numpy 2)
+        NaN = float("nan")
+
+    ns = dict(Counter=Counter, math=math, copy=copy, gzip=gzip, logging=logging, pickle=pickle,
+              sys=sys, os=os, itertools=itertools, np=_NP, LETTERS=("A", "T", "G", "C"))
+    exec(compile(mod, "<reference hot path via lib2to3>", "exec"), ns)
+    shutil.rmtree(scratch)
+    return ns
+
+
+class Args:
+    def __init__(self, hostSeq, querySeq=None, m=1, k=8, w=5000, i=2500, maskHost=False,
+                 scaffoldsAll=False, RIP=False, tempDir="."):
+        self.hostSeq = hostSeq
+        self.querySeq = querySeq
+        self.minWordSize = m
+        self.maxWordSize = k
+        self.windowlen = w
+        self.increment = i
+        self.maskHost = maskHost
+        self.scaffoldsAll = scaffoldsAll
+        self.RIP = RIP
+        self.tempDir = tempDir
+
+
+def code_to_kmer(code, x):
+    return "".join("ATGC"[(code >> (2 * (x - 1 - p))) & 3] for p in range(x))
+
+
+def flatten(maps, m, k):
+    """list-of-dicts -> int64[sum 4^x], canonical order A,T,G,C = 0..3, first base most significant."""
+    out = []
+    for x in range(m, k + 1):
+        d = maps[x - m]
+        assert len(d) == 4 ** x
+        out.extend(d[code_to_kmer(c, x)] for c in range(4 ** x))
+    return np.asarray(out, dtype=np.int64)
+
+
+def meta(maps, m, k):
+    r = k - m
+    return [maps[r + 1]["totalLen"], maps[r + 2]["exMax"], maps[r + 3]["nnTotal"]]
+
+
+def dense(d, k):
+    v = np.zeros(4 ** k, dtype=np.float64)
+    for kmer, val in d.items():
+        c = 0
+        for ch in kmer:
+            c = (c << 2) | "ATGC".index(ch)
+        v[c] = val
+    return v
+
+
+CASES = [
+    # name, host, query, kwargs, store_ivom
+    ("kat", "kat.fa", None, dict(m=1, k=3, w=20, i=8, RIP=True), True),
+    ("uniform_k4", "uniform3k.fa", None, dict(m=1, k=4, w=500, i=100, RIP=True), True),
+    ("markov_k6", "markov_islands.fa", None, dict(m=1, k=6, w=400, i=150, RIP=True), False),
+    ("markov_k5_i100", "markov_islands.fa", None, dict(m=1, k=5, w=400, i=100), False),
+    ("markov_m2k4", "markov_islands.fa", None, dict(m=2, k=4, w=400, i=150, RIP=True), True),
+    ("markov_m3k3", "markov_islands.fa", None, dict(m=3, k=3, w=400, i=150), True),
+    ("markov_m3k5", "markov_islands.fa", None, dict(m=3, k=5, w=400, i=150), False),
+    ("smalls_skip", "smalls.fa", None, dict(m=1, k=4, w=400, i=150, RIP=True), False),
+    ("smalls_all", "smalls.fa", None, dict(m=1, k=4, w=400, i=150, RIP=True, scaffoldsAll=True), False),
+    ("smalls_all_k8", "smalls.fa", None, dict(m=1, k=8, w=400, i=150, scaffoldsAll=True), False),
+    ("nheavy_k4", "nheavy.fa", None, dict(m=1, k=4, w=400, i=100, RIP=True), False),
+    ("maskhost", "host.fa", None, dict(m=1, k=5, w=500, i=250, maskHost=True), False),
+    ("hq_k6", "host.fa", "query.fa", dict(m=1, k=6, w=500, i=100, RIP=True), False),
+    ("hq_m5k6_zero", "host.fa", "query.fa", dict(m=5, k=6, w=500, i=100), False),
+    ("k7", "k8.fa", None, dict(m=1, k=7, w=3000, i=700, RIP=True), False),
+    ("k8", "k8.fa", None, dict(m=1, k=8, w=5000, i=1000, RIP=True), False),
+    ("k8_w2000", "k8.fa", None, dict(m=1, k=8, w=2000, i=500), False),
+    ("k8_m2", "k8.fa", None, dict(m=2, k=8, w=5000, i=2500, RIP=True), False),
+]
+
+
+def run_case(ns, name, host, query, kw, store_ivom):
+    tmp = tempfile.mkdtemp(prefix="frisk_gold_")
+    a = Args(os.path.join(INP, host), os.path.join(INP, query) if query else None, tempDir=tmp, **kw)
+    m, k = a.minWordSize, a.maxWordSize
+    querySeq = a.querySeq if a.querySeq else a.hostSeq
+    blankMap = ns["rangeMaps"](m, k)
+    # phase A: frisk/__init__.py:1442
+    genomepickle = ns["makePicklePath"](a, space="genome")
+    genomeKmers = ns["computeKmers"](a, genomepickle=genomepickle, window=None, genomeMode=True,
+                                     kmerMap=blankMap, getMeta=True)
+    arrays = {"genome_counts": flatten(genomeKmers, m, k)}
+    out = {
+        "case": name, "host": host, "query": query,
+        "args": dict(minWordSize=m, maxWordSize=k, windowlen=a.windowlen, increment=a.increment,
+                     maskHost=a.maskHost, scaffoldsAll=a.scaffoldsAll, RIP=a.RIP),
+        "genome_meta": meta(genomeKmers, m, k),
+        "genome_pickle_basename": os.path.basename(genomepickle),
+        "window_pickle_basename": os.path.basename(ns["makePicklePath"](a, space="window")),
+        "rows": [],
+    }
+    win_counts, w_ivom, g_ivom = [], [], []
+    rip_on = a.RIP and m <= 2
+    # phase B: frisk/__init__.py:1478-1494
+    for seq, sname, start, stop in ns["crawlGenome"](a, querySeq):
+        row = {"name": sname, "start": start, "stop": stop}
+        windowKmers = ns["computeKmers"](a, genomepickle=None, window=[(sname, seq)], genomeMode=False,
+                                         kmerMap=blankMap, getMeta=True)
+        win_counts.append(flatten(windowKmers, m, k))
+        row["meta"] = meta(windowKmers, m, k)
+        try:
+            GenomeIVOM = ns["IvomBuild"](windowKmers, a, genomeKmers, True)
+            windowIVOM = ns["IvomBuild"](windowKmers, a, genomeKmers, False)
+            row["KLD"] = ns["KLD"](GenomeIVOM, windowIVOM, a)
+            if store_ivom:
+                w_ivom.append(dense(windowIVOM, k))
+                g_ivom.append(dense(GenomeIVOM, k))
+        except ZeroDivisionError:
+            row["error"] = "ZeroDivisionError"
+            if store_ivom:
+                w_ivom.append(np.zeros(4 ** k))
+                g_ivom.append(np.zeros(4 ** k))
+        try:
+            row["GC"] = ns["calcGC"](seq)
+        except ZeroDivisionError:
+            row["GC_error"] = "ZeroDivisionError"
+        if rip_on:
+            PI, SI, CRI = ns["calcRIP"](windowKmers, a)
+            row["RIP"] = [PI, SI, CRI]
+            # the table text the reference writes (py3 str(); py2 differs only in float digits)
+        out["rows"].append(row)
+    arrays["window_counts"] = (np.stack(win_counts).astype(np.int32) if win_counts
+                               else np.zeros((0, arrays["genome_counts"].size), np.int32))
+    if store_ivom:
+        arrays["window_ivom"] = np.stack(w_ivom) if w_ivom else np.zeros((0, 4 ** k))
+        arrays["genome_ivom"] = np.stack(g_ivom) if g_ivom else np.zeros((0, 4 ** k))
+    shutil.rmtree(tmp)
+    with open(os.path.join(GOLD, name + ".json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+        fh.write("\n")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
+    nerr = sum(1 for r in out["rows"] if "error" in r)
+    print("%-16s rows=%-4d errors=%-3d genome_meta=%s" % (name, len(out["rows"]), nerr, out["genome_meta"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*")
+    opts = ap.parse_args()
+    logging.basicConfig(level=logging.WARNING)
+    ns = load_reference_functions()
+    for name, host, query, kw, store_ivom in CASES:
+        if opts.cases and name not in opts.cases:
+            continue
+        run_case(ns, name, host, query, kw, store_ivom)
+
+
+if __name__ == "__main__":
+    main()
