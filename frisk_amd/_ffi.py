@@ -1,0 +1,70 @@
+"""ctypes binding of libfrisk_hip.so (C ABI: include/frisk_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded this
+module raises at first use, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrisk_hip.so")
+
+OK, E_ARG, E_HIP, E_STATE, E_CAP, E_ZERO_WEIGHT = 0, -1, -2, -3, -4, -5
+SCAN_RIP, SCAN_SCAFFOLDS_ALL = 1, 2
+ROW_KEPT, ROW_ZERO_WEIGHT, ROW_JUMPBACK, ROW_NO_MAXMER = 1, 2, 4, 8
+
+# every symbol include/frisk_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_I64P = C.POINTER(C.c_int64)
+SYMBOLS = [
+    ("frisk_version", C.c_char_p, []),
+    ("frisk_supported", C.c_int, [C.c_int, C.c_int, C.c_int64]),
+    ("frisk_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("frisk_destroy", None, [_P]),
+    ("frisk_last_error", C.c_char_p, [_P]),
+    ("frisk_profile_len", C.c_int64, [_P]),
+    ("frisk_seq_load", C.c_int, [_P, C.POINTER(C.c_char_p), _I64P, C.c_int32]),
+    ("frisk_seq_synth", C.c_int, [_P, _I64P, C.c_int32, C.c_uint64, C.c_double, C.c_double, C.c_double]),
+    ("frisk_seq_read", C.c_int, [_P, C.c_int32, _P, C.c_int64]),
+    ("frisk_profile_reset", C.c_int, [_P]),
+    ("frisk_profile_add", C.c_int, [_P, C.c_int, C.c_int64, C.c_int64]),
+    ("frisk_seq_padded_len", C.c_int64, [_P]),
+    ("frisk_profile_raw_len", C.c_int64, [_P]),
+    ("frisk_profile_export_device", C.c_int, [_P, _P]),
+    ("frisk_profile_import_device", C.c_int, [_P, _P]),
+    ("frisk_profile_export_host", C.c_int, [_P, _P]),
+    ("frisk_profile_import_host", C.c_int, [_P, _P]),
+    ("frisk_profile_finalize", C.c_int, [_P]),
+    ("frisk_profile_get", C.c_int, [_P, _P, _I64P, _I64P, _I64P]),
+    ("frisk_profile_set", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64]),
+    ("frisk_scan_plan", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, _I64P]),
+    ("frisk_scan", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64,
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("frisk_last_kernel_ms", C.c_double, [_P, C.c_int]),
+]
+
+_lib = None
+
+
+class FriskHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libfrisk_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+def lib():
+    """Load the library once; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "frisk_amd has no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib

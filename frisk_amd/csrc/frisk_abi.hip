@@ -1,0 +1,565 @@
+// frisk_abi.hip - host side of libfrisk_hip.so: the C ABI declared in include/frisk_hip.h.
+// gfx950 (MI355X) only.  Build: see __graft_entry__.build().
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "frisk_hip.h"
+#include "frisk_device.h"
+#include "profile_kernels.h"
+#include "scan_kernel.h"
+#include "synth_kernel.h"
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;     // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct frisk_ctx {
+    int device = 0;
+    int kmin = 1, kmax = 8;
+    int64_t nprof = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double ms[3] = {-1.0, -1.0, -1.0};
+    std::string err;
+
+    // resident batch
+    int32_t n_seq = 0;
+    std::vector<int64_t> seq_off, seq_len;
+    int64_t padded_len = 0;
+    bool have_seq = false;
+    DevBuf<uint8_t> d_ascii;
+    DevBuf<uint32_t> d_codes, d_inv, d_low;
+
+    // profile
+    DevBuf<int64_t> d_raw, d_cnt, d_sym;
+    DevBuf<double> d_ig;
+    int64_t total_len = 0, ex_max = 0, nn_total = 0;
+    bool profile_final = false;
+
+    // scan plan + outputs
+    DevBuf<ScafDesc> d_desc;
+    std::vector<ScafDesc> h_desc;
+    int32_t plan_w = -1, plan_inc = -1;
+    uint32_t plan_flags = 0;
+    int64_t plan_ncand = 0;
+    int64_t plan_maxwin = 0;
+    DevBuf<int32_t> o_seq;
+    DevBuf<int64_t> o_start, o_stop, o_meta;
+    DevBuf<uint32_t> o_status, o_counts;
+    DevBuf<double> o_kld, o_gc, o_pi, o_si, o_cri;
+};
+
+namespace {
+
+int fail(frisk_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPC(ctx, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((ctx), FRISK_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int64_t profile_len(int kmin, int kmax) { return table_offset(kmin, kmax + 1); }
+
+int grid_for(int64_t items, int per_block, int max_blocks) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return int(b);
+}
+
+// common tail of frisk_seq_load / frisk_seq_synth: allocate + pack
+int alloc_packed(frisk_ctx* c) {
+    const size_t w32 = size_t(c->padded_len / 32);
+    HIPC(c, c->d_codes.reserve(2 * w32 + 8));
+    HIPC(c, c->d_inv.reserve(w32 + 8));
+    HIPC(c, c->d_low.reserve(w32 + 8));
+    // tail words past the batch: codes 0, inv/low all ones (= PAD), so a run can never extend past the end
+    HIPC(c, hipMemsetAsync(c->d_codes.p + 2 * w32, 0, 8 * sizeof(uint32_t), c->stream));
+    HIPC(c, hipMemsetAsync(c->d_inv.p + w32, 0xFF, 8 * sizeof(uint32_t), c->stream));
+    HIPC(c, hipMemsetAsync(c->d_low.p + w32, 0xFF, 8 * sizeof(uint32_t), c->stream));
+    return FRISK_OK;
+}
+
+int run_pack(frisk_ctx* c) {
+    const int64_t w32 = c->padded_len / 32;
+    HIPC(c, hipEventRecord(c->ev0, c->stream));
+    if (w32 > 0)
+        pack_kernel<<<grid_for(w32, 256, c->num_cu * 8), 256, 0, c->stream>>>(c->d_ascii.p, w32, c->d_codes.p,
+                                                                               c->d_inv.p, c->d_low.p);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipEventRecord(c->ev1, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->ms[2] = ms;
+    c->have_seq = true;
+    c->plan_w = -1;
+    return FRISK_OK;
+}
+
+int layout_batch(frisk_ctx* c, const int64_t* lens, int32_t n_seq) {
+    if (n_seq < 0) return fail(c, FRISK_E_ARG, "n_seq < 0");
+    c->seq_off.assign(size_t(n_seq), 0);
+    c->seq_len.assign(lens, lens + n_seq);
+    int64_t pos = 0;
+    for (int32_t s = 0; s < n_seq; ++s) {
+        if (lens[s] < 0) return fail(c, FRISK_E_ARG, "negative scaffold length");
+        c->seq_off[size_t(s)] = pos;
+        pos += lens[s] + 1;                       // at least one PAD position after every scaffold
+    }
+    c->padded_len = (pos + 31) / 32 * 32;
+    if (c->padded_len == 0) c->padded_len = 32;
+    c->n_seq = n_seq;
+    c->have_seq = false;
+    return FRISK_OK;
+}
+
+// candidate windows of one scaffold (crawlGenome, L194-251)
+void plan_scaffold(int64_t size, int32_t w, int32_t inc, bool all, int64_t& ncand, int32_t& kind) {
+    const double limit = double(w) + ((double(w) * 0.75) - double(inc));      // L211 / L222, evaluated as CPython does
+    if (double(size) <= limit) {
+        kind = 1;
+        ncand = all ? 1 : 0;
+    } else {
+        kind = 0;
+        ncand = (size - inc + 1 > 0) ? (size - inc) / inc + 1 : 0;            // len(range(0, size-inc+1, inc)), L228
+    }
+}
+
+template <bool K8, int ITS, bool DEBUG>
+hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st) {
+    auto kern = scan_kernel<K8, ITS, DEBUG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(lds));
+    if (e != hipSuccess) return e;
+    kern<<<grid, FRISK_SCAN_NT, lds, st>>>(P);
+    return hipGetLastError();
+}
+
+int build_genome_table(frisk_ctx* c) {
+    const int64_t n = int64_t(1) << (2 * c->kmax);
+    const int64_t genome_space = c->total_len - c->nn_total;                    // L379
+    genome_ivom_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(c->d_sym.p, c->kmin, c->kmax, genome_space,
+                                                                          c->d_ig.p);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->profile_final = true;
+    return FRISK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* frisk_version(void) { return "frisk_hip 0.1 (gfx950)"; }
+
+int frisk_supported(int kmin, int kmax, int64_t max_window) {
+    return (kmin >= 1 && kmin <= kmax && kmax <= FRISK_MAX_K && max_window >= 1 && max_window <= 65535) ? 1 : 0;
+}
+
+int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
+    if (!out) return FRISK_E_ARG;
+    *out = nullptr;
+    frisk_ctx* c = new (std::nothrow) frisk_ctx();
+    if (!c) return FRISK_E_HIP;
+    *out = c;       // returned even on failure so that frisk_last_error() can be read; caller destroys it
+    if (kmin < 1 || kmin > kmax || kmax > FRISK_MAX_K)
+        return fail(c, FRISK_E_ARG, "word sizes must satisfy 1 <= kmin <= kmax <= 8");
+    c->device = device;
+    c->kmin = kmin;
+    c->kmax = kmax;
+    c->nprof = profile_len(kmin, kmax);
+    int ndev = 0;
+    HIPC(c, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(c, FRISK_E_HIP, "no such HIP device");
+    HIPC(c, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPC(c, hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(c, FRISK_E_HIP, std::string("libfrisk_hip is built for gfx950 only; device is ") + prop.gcnArchName);
+    c->num_cu = prop.multiProcessorCount;
+    HIPC(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPC(c, hipEventCreate(&c->ev0));
+    HIPC(c, hipEventCreate(&c->ev1));
+    HIPC(c, c->d_raw.reserve(size_t(c->nprof) + 4));
+    HIPC(c, c->d_cnt.reserve(size_t(c->nprof) + 4));
+    HIPC(c, c->d_sym.reserve(size_t(c->nprof)));
+    HIPC(c, c->d_ig.reserve(size_t(1) << (2 * kmax)));
+    HIPC(c, hipMemsetAsync(c->d_raw.p, 0, (size_t(c->nprof) + 4) * sizeof(int64_t), c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FRISK_OK;
+}
+
+void frisk_destroy(frisk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->d_ascii.release(); c->d_codes.release(); c->d_inv.release(); c->d_low.release();
+    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_desc.release();
+    c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
+    c->o_status.release(); c->o_counts.release();
+    c->o_kld.release(); c->o_gc.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* frisk_last_error(const frisk_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int64_t frisk_profile_len(const frisk_ctx* c) { return c ? c->nprof : 0; }
+int64_t frisk_profile_raw_len(const frisk_ctx* c) { return c ? c->nprof + 4 : 0; }
+int64_t frisk_seq_padded_len(const frisk_ctx* c) { return (c && c->have_seq) ? c->padded_len : 0; }
+double frisk_last_kernel_ms(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 3) ? c->ms[which] : -1.0; }
+
+// ------------------------------------------------------------------------------------- sequences
+int frisk_seq_load(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq) {
+    if (!c) return FRISK_E_ARG;
+    if (n_seq > 0 && (!seqs || !lens)) return fail(c, FRISK_E_ARG, "null sequence table");
+    HIPC(c, hipSetDevice(c->device));
+    int rc = layout_batch(c, lens, n_seq);
+    if (rc) return rc;
+    HIPC(c, c->d_ascii.reserve(size_t(c->padded_len)));
+    if (n_seq <= 64) {
+        HIPC(c, hipMemsetAsync(c->d_ascii.p, FRISK_PAD_BYTE, size_t(c->padded_len), c->stream));
+        for (int32_t s = 0; s < n_seq; ++s)
+            if (lens[s] > 0)
+                HIPC(c, hipMemcpyAsync(c->d_ascii.p + c->seq_off[size_t(s)], seqs[s], size_t(lens[s]),
+                                       hipMemcpyHostToDevice, c->stream));
+    } else {            // many small scaffolds: assemble once on the host, one copy
+        std::vector<uint8_t> stage(size_t(c->padded_len), uint8_t(FRISK_PAD_BYTE));
+        for (int32_t s = 0; s < n_seq; ++s)
+            if (lens[s] > 0) std::memcpy(stage.data() + c->seq_off[size_t(s)], seqs[s], size_t(lens[s]));
+        HIPC(c, hipMemcpyAsync(c->d_ascii.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    rc = alloc_packed(c);
+    if (rc) return rc;
+    return run_pack(c);
+}
+
+int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t seed, double island_frac,
+                    double n_frac, double lower_frac) {
+    if (!c) return FRISK_E_ARG;
+    if (n_seq > 0 && !lens) return fail(c, FRISK_E_ARG, "null length table");
+    HIPC(c, hipSetDevice(c->device));
+    int rc = layout_batch(c, lens, n_seq);
+    if (rc) return rc;
+    HIPC(c, c->d_ascii.reserve(size_t(c->padded_len)));
+    HIPC(c, hipMemsetAsync(c->d_ascii.p, FRISK_PAD_BYTE, size_t(c->padded_len), c->stream));
+    SynthTables tabs;
+    synth_make_tables(seed, tabs);
+    const uint32_t thr_island = synth_frac_to_u32(island_frac), thr_nbig = synth_frac_to_u32(n_frac * 0.8),
+                   thr_nsmall = synth_frac_to_u32(n_frac * 0.2), thr_low = synth_frac_to_u32(lower_frac);
+    for (int32_t s = 0; s < n_seq; ++s) {
+        if (lens[s] <= 0) continue;
+        const int64_t nblk = (lens[s] + SYNTH_BLOCK - 1) / SYNTH_BLOCK;
+        synth_kernel<<<grid_for(nblk, 64, 1 << 20), 64, 0, c->stream>>>(c->d_ascii.p + c->seq_off[size_t(s)], lens[s],
+                                                                       seed, uint32_t(s), tabs, thr_island, thr_nbig,
+                                                                       thr_nsmall, thr_low);
+        HIPC(c, hipGetLastError());
+    }
+    rc = alloc_packed(c);
+    if (rc) return rc;
+    return run_pack(c);
+}
+
+int frisk_seq_read(frisk_ctx* c, int32_t s, uint8_t* out, int64_t cap) {
+    if (!c || !out) return FRISK_E_ARG;
+    if (!c->have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
+    if (s < 0 || s >= c->n_seq) return fail(c, FRISK_E_ARG, "sequence index out of range");
+    const int64_t n = c->seq_len[size_t(s)];
+    if (cap < n) return fail(c, FRISK_E_CAP, "buffer too small: need " + std::to_string(n));
+    if (n == 0) return FRISK_OK;
+    HIPC(c, hipSetDevice(c->device));
+    DevBuf<uint8_t> tmp;
+    HIPC(c, tmp.reserve(size_t(n)));
+    unpack_kernel<<<grid_for(n, 256, c->num_cu * 8), 256, 0, c->stream>>>(c->d_codes.p, c->d_inv.p, c->d_low.p,
+                                                                           c->seq_off[size_t(s)], n, tmp.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp.p, size_t(n), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    tmp.release();
+    HIPC(c, e);
+    return FRISK_OK;
+}
+
+// --------------------------------------------------------------------------------------- phase A
+int frisk_profile_reset(frisk_ctx* c) {
+    if (!c) return FRISK_E_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemsetAsync(c->d_raw.p, 0, (size_t(c->nprof) + 4) * sizeof(int64_t), c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->profile_final = false;
+    return FRISK_OK;
+}
+
+int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
+    if (!c) return FRISK_E_ARG;
+    if (!c->have_seq) return fail(c, FRISK_E_STATE, "frisk_profile_add: no resident sequence batch");
+    if (p0 < 0 && p1 < 0) { p0 = 0; p1 = c->padded_len; }
+    if (p0 < 0 || p1 > c->padded_len || p0 > p1) return fail(c, FRISK_E_ARG, "position range outside the batch");
+    HIPC(c, hipSetDevice(c->device));
+    c->profile_final = false;
+    const bool lds_hist = c->nprof <= 8192;
+    const int grid = grid_for(p1 - p0, 256 * 16, c->num_cu * 8);
+    HIPC(c, hipEventRecord(c->ev0, c->stream));
+    if (p1 > p0) {
+        auto raw = reinterpret_cast<unsigned long long*>(c->d_raw.p);
+        if (lds_hist)
+            profile_add_kernel<true><<<grid, 256, size_t(c->nprof) * 4, c->stream>>>(
+                c->d_codes.p, c->d_inv.p, c->d_low.p, p0, p1, c->kmin, c->kmax, mask_host ? 1 : 0, int(c->nprof), raw);
+        else
+            profile_add_kernel<false><<<grid, 256, 0, c->stream>>>(c->d_codes.p, c->d_inv.p, c->d_low.p, p0, p1, c->kmin,
+                                                                  c->kmax, mask_host ? 1 : 0, int(c->nprof), raw);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipEventRecord(c->ev1, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->ms[1] = ms;
+    return FRISK_OK;
+}
+
+int frisk_profile_export_device(frisk_ctx* c, void* dst) {
+    if (!c || !dst) return FRISK_E_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(dst, c->d_raw.p, (size_t(c->nprof) + 4) * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FRISK_OK;
+}
+int frisk_profile_import_device(frisk_ctx* c, const void* src) {
+    if (!c || !src) return FRISK_E_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(c->d_raw.p, src, (size_t(c->nprof) + 4) * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->profile_final = false;
+    return FRISK_OK;
+}
+int frisk_profile_export_host(frisk_ctx* c, int64_t* dst) {
+    if (!c || !dst) return FRISK_E_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(dst, c->d_raw.p, (size_t(c->nprof) + 4) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FRISK_OK;
+}
+int frisk_profile_import_host(frisk_ctx* c, const int64_t* src) {
+    if (!c || !src) return FRISK_E_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(c->d_raw.p, src, (size_t(c->nprof) + 4) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->profile_final = false;
+    return FRISK_OK;
+}
+
+int frisk_profile_finalize(frisk_ctx* c) {
+    if (!c) return FRISK_E_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    const size_t nraw = size_t(c->nprof) + 4;
+    HIPC(c, hipMemcpyAsync(c->d_cnt.p, c->d_raw.p, nraw * 8, hipMemcpyDeviceToDevice, c->stream));
+    for (int x = c->kmax - 1; x >= c->kmin; --x) {
+        const int64_t n = int64_t(1) << (2 * x);
+        marginalize_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(c->d_cnt.p, c->kmin, x);
+    }
+    symmetrize_kernel<<<grid_for(c->nprof, 256, 1 << 20), 256, 0, c->stream>>>(c->d_cnt.p, c->d_sym.p, c->kmin, c->kmax);
+    HIPC(c, hipGetLastError());
+    // metadata of L356-359: totalLen, exMax = K-mer start positions that were NOT counted, nnTotal
+    std::vector<int64_t> top(size_t(1) << (2 * c->kmax));
+    int64_t tail[4];
+    HIPC(c, hipMemcpyAsync(top.data(), c->d_cnt.p + table_offset(c->kmin, c->kmax), top.size() * 8,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(tail, c->d_raw.p + c->nprof, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    int64_t counted = 0;
+    for (int64_t v : top) counted += v;
+    c->total_len = tail[0];
+    c->ex_max = tail[1] - counted;
+    c->nn_total = tail[2];
+    return build_genome_table(c);
+}
+
+int frisk_profile_get(frisk_ctx* c, int64_t* sym, int64_t* total_len, int64_t* ex_max, int64_t* nn_total) {
+    if (!c) return FRISK_E_ARG;
+    if (!c->profile_final) return fail(c, FRISK_E_STATE, "profile not finalised");
+    HIPC(c, hipSetDevice(c->device));
+    if (sym) {
+        HIPC(c, hipMemcpyAsync(sym, c->d_sym.p, size_t(c->nprof) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    if (total_len) *total_len = c->total_len;
+    if (ex_max) *ex_max = c->ex_max;
+    if (nn_total) *nn_total = c->nn_total;
+    return FRISK_OK;
+}
+
+int frisk_profile_set(frisk_ctx* c, const int64_t* sym, int64_t total_len, int64_t ex_max, int64_t nn_total) {
+    if (!c || !sym) return FRISK_E_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(c->d_sym.p, sym, size_t(c->nprof) * 8, hipMemcpyHostToDevice, c->stream));
+    c->total_len = total_len;
+    c->ex_max = ex_max;
+    c->nn_total = nn_total;
+    return build_genome_table(c);
+}
+
+// --------------------------------------------------------------------------------------- phase B
+int frisk_scan_plan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t* n_candidates) {
+    if (!c) return FRISK_E_ARG;
+    if (!c->have_seq) return fail(c, FRISK_E_STATE, "frisk_scan_plan: no resident sequence batch");
+    if (w < 1 || inc < 1) return fail(c, FRISK_E_ARG, "window length and increment must be >= 1");
+    if (w > 65535) return fail(c, FRISK_E_ARG, "window length > 65535 is not supported by the LDS kernel");
+    const bool all = (flags & FRISK_SCAN_SCAFFOLDS_ALL) != 0;
+    if (c->plan_w == w && c->plan_inc == inc && ((c->plan_flags ^ flags) & FRISK_SCAN_SCAFFOLDS_ALL) == 0) {
+        if (n_candidates) *n_candidates = c->plan_ncand;
+        return FRISK_OK;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    c->h_desc.assign(size_t(c->n_seq) + 1, ScafDesc());
+    int64_t cand = 0, maxwin = 0;
+    for (int32_t s = 0; s < c->n_seq; ++s) {
+        ScafDesc& d = c->h_desc[size_t(s)];
+        d.off = c->seq_off[size_t(s)];
+        d.size = c->seq_len[size_t(s)];
+        d.cand0 = cand;
+        plan_scaffold(d.size, w, inc, all, d.ncand, d.kind);
+        d.pad_ = 0;
+        if (d.ncand > 0) maxwin = std::max<int64_t>(maxwin, d.kind == 1 ? d.size : w);
+        cand += d.ncand;
+    }
+    ScafDesc& sentinel = c->h_desc[size_t(c->n_seq)];       // keeps the binary search in range
+    sentinel.off = c->padded_len; sentinel.size = 0; sentinel.cand0 = cand; sentinel.ncand = 0; sentinel.kind = 0;
+    sentinel.pad_ = 0;
+    if (maxwin > 65535) return fail(c, FRISK_E_ARG, "a rescued scaffold is longer than 65535 bases");
+    HIPC(c, c->d_desc.reserve(c->h_desc.size()));
+    HIPC(c, hipMemcpyAsync(c->d_desc.p, c->h_desc.data(), c->h_desc.size() * sizeof(ScafDesc), hipMemcpyHostToDevice,
+                           c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->plan_w = w; c->plan_inc = inc; c->plan_flags = flags; c->plan_ncand = cand; c->plan_maxwin = maxwin;
+    if (n_candidates) *n_candidates = cand;
+    return FRISK_OK;
+}
+
+int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1, int64_t cap,
+               int32_t* seq_index, int64_t* start, int64_t* stop, uint32_t* status, double* kld, double* gc,
+               double* pi, double* si, double* cri, uint32_t* dbg_counts, int64_t* dbg_meta) {
+    if (!c) return FRISK_E_ARG;
+    if (!c->profile_final) return fail(c, FRISK_E_STATE, "frisk_scan: genome profile not finalised");
+    int64_t ncand_all = 0;
+    int rc = frisk_scan_plan(c, w, inc, flags, &ncand_all);
+    if (rc) return rc;
+    if (c1 < 0) c1 = ncand_all;
+    if (c0 < 0 || c0 > c1 || c1 > ncand_all) return fail(c, FRISK_E_ARG, "candidate range outside [0, n_candidates]");
+    const int64_t n = c1 - c0;
+    if (cap < n) return fail(c, FRISK_E_CAP, "output capacity too small: need " + std::to_string(n));
+    const bool rip = (flags & FRISK_SCAN_RIP) != 0;
+    if (rip && !(c->kmin <= 2 && c->kmax >= 2))
+        return fail(c, FRISK_E_ARG, "RIP indices need dinucleotide counts: kmin <= 2 <= kmax (reference L478)");
+    if (rip && (!pi || !si || !cri)) return fail(c, FRISK_E_ARG, "FRISK_SCAN_RIP needs pi/si/cri buffers");
+    if (!seq_index || !start || !stop || !status || !kld || !gc) return fail(c, FRISK_E_ARG, "null output buffer");
+    c->ms[0] = 0.0;
+    if (n == 0) return FRISK_OK;
+    HIPC(c, hipSetDevice(c->device));
+    const bool debug = dbg_counts || dbg_meta;
+    const size_t N = size_t(n);
+    HIPC(c, c->o_seq.reserve(N)); HIPC(c, c->o_start.reserve(N)); HIPC(c, c->o_stop.reserve(N));
+    HIPC(c, c->o_status.reserve(N)); HIPC(c, c->o_kld.reserve(N)); HIPC(c, c->o_gc.reserve(N));
+    if (rip) { HIPC(c, c->o_pi.reserve(N)); HIPC(c, c->o_si.reserve(N)); HIPC(c, c->o_cri.reserve(N)); }
+    if (dbg_counts) {
+        HIPC(c, c->o_counts.reserve(N * size_t(c->nprof)));
+        HIPC(c, hipMemsetAsync(c->o_counts.p, 0, N * size_t(c->nprof) * 4, c->stream));
+    }
+    if (dbg_meta) {
+        HIPC(c, c->o_meta.reserve(N * 3));
+        HIPC(c, hipMemsetAsync(c->o_meta.p, 0, N * 3 * 8, c->stream));
+    }
+
+    ScanParams P;
+    P.codes = c->d_codes.p; P.inv = c->d_inv.p; P.low = c->d_low.p;
+    P.descs = c->d_desc.p; P.ig = c->d_ig.p;
+    P.n_desc = c->n_seq + 1;
+    P.kmin = c->kmin; P.kmax = c->kmax; P.w = w; P.inc = inc; P.flags = flags; P.c0 = c0; P.c1 = c1;
+    P.orphan_cap = int32_t(c->plan_maxwin / 8 + 2);
+    P.nprof = int32_t(c->nprof);
+    P.seq_index = c->o_seq.p; P.start = c->o_start.p; P.stop = c->o_stop.p; P.status = c->o_status.p;
+    P.kld = c->o_kld.p; P.gc = c->o_gc.p;
+    P.pi = rip ? c->o_pi.p : nullptr; P.si = rip ? c->o_si.p : nullptr; P.cri = rip ? c->o_cri.p : nullptr;
+    P.dbg_counts = dbg_counts ? c->o_counts.p : nullptr;
+    P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
+
+    const bool k8 = (c->kmax == 8);
+    const LdsLayout L = make_layout(c->kmin, c->kmax, P.orphan_cap);
+    const int wg_per_cu = std::max(1, std::min(2, int(160 * 1024 / L.total)));
+    int grid = int(std::min<int64_t>(n, int64_t(c->num_cu) * wg_per_cu));
+    if (grid >= 8) grid &= ~7;
+    int64_t chunk = n / (int64_t(grid) * 8);
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, 16));
+    P.chunk = int32_t(chunk);
+    const bool keep_regs = c->plan_maxwin <= 8 * FRISK_SCAN_NT;
+
+    HIPC(c, hipEventRecord(c->ev0, c->stream));
+    hipError_t e;
+    if (k8) {
+        if (debug) e = keep_regs ? launch_scan<true, 8, true>(P, grid, L.total, c->stream)
+                                 : launch_scan<true, 0, true>(P, grid, L.total, c->stream);
+        else e = keep_regs ? launch_scan<true, 8, false>(P, grid, L.total, c->stream)
+                           : launch_scan<true, 0, false>(P, grid, L.total, c->stream);
+    } else {
+        if (debug) e = keep_regs ? launch_scan<false, 8, true>(P, grid, L.total, c->stream)
+                                 : launch_scan<false, 0, true>(P, grid, L.total, c->stream);
+        else e = keep_regs ? launch_scan<false, 8, false>(P, grid, L.total, c->stream)
+                           : launch_scan<false, 0, false>(P, grid, L.total, c->stream);
+    }
+    HIPC(c, e);
+    HIPC(c, hipEventRecord(c->ev1, c->stream));
+
+    HIPC(c, hipMemcpyAsync(seq_index, c->o_seq.p, N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(start, c->o_start.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(stop, c->o_stop.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(status, c->o_status.p, N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(kld, c->o_kld.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(gc, c->o_gc.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (rip) {
+        HIPC(c, hipMemcpyAsync(pi, c->o_pi.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipMemcpyAsync(si, c->o_si.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipMemcpyAsync(cri, c->o_cri.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (dbg_counts)
+        HIPC(c, hipMemcpyAsync(dbg_counts, c->o_counts.p, N * size_t(c->nprof) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (dbg_meta) HIPC(c, hipMemcpyAsync(dbg_meta, c->o_meta.p, N * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->ms[0] = ms;
+    return FRISK_OK;
+}
+
+}  // extern "C"

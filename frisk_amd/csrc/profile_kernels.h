@@ -1,0 +1,174 @@
+// profile_kernels.h - pack / unpack of scaffolds and phase A (genome k-mer profile) kernels.
+// Reference semantics: computeKmers(genomeMode=True), frisk/__init__.py L280-367, called at L1442.
+#pragma once
+#include "frisk_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// ASCII -> (codes, inv, low).  One thread packs 32 consecutive bases (two 16-byte loads, coalesced
+// across the wave: 2 KiB of ASCII per wave-instruction pair) and writes two code words + one word of
+// each mask.  HBM-bound: 1 B/base read, 0.5 B/base written.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void classify_byte(uint32_t c, uint32_t& code, uint32_t& inv, uint32_t& low) {
+    const uint32_t u = c & 0xDFu;                       // fold ASCII case
+    const uint32_t isA = (u == 'A'), isT = (u == 'T'), isG = (u == 'G'), isC = (u == 'C');
+    const uint32_t valid = isA | isT | isG | isC;
+    code = isT * 1u + isG * 2u + isC * 3u;              // A=0,T=1,G=2,C=3 (reference L70)
+    const uint32_t is_pad = (c == FRISK_PAD_BYTE);
+    inv = (valid ^ 1u);
+    low = (valid & ((c >> 5) & 1u)) | is_pad;           // lowercase acgt, or PAD (inv & low)
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ ascii, int64_t nwords32,
+                                                    uint32_t* __restrict__ codes, uint32_t* __restrict__ inv,
+                                                    uint32_t* __restrict__ low) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < nwords32; t += stride) {
+        const uint4* src = reinterpret_cast<const uint4*>(ascii + t * 32);
+        const uint4 q0 = src[0], q1 = src[1];
+        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        uint32_t c0 = 0, c1 = 0, mi = 0, ml = 0;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            const uint32_t ch = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+            uint32_t code, i1, l1;
+            classify_byte(ch, code, i1, l1);
+            if (b < 16) c0 |= code << (30 - 2 * b); else c1 |= code << (30 - 2 * (b - 16));
+            mi |= i1 << (31 - b);
+            ml |= l1 << (31 - b);
+        }
+        codes[2 * t] = c0;
+        codes[2 * t + 1] = c1;
+        inv[t] = mi;
+        low[t] = ml;
+    }
+}
+
+// packed -> canonical ASCII (A/T/G/C, a/t/g/c, N; PAD -> '\0'): test / read-back utility
+__global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict__ codes,
+                                                      const uint32_t* __restrict__ inv,
+                                                      const uint32_t* __restrict__ low, int64_t p0, int64_t n,
+                                                      uint8_t* __restrict__ out) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const int64_t g = p0 + t;
+        const uint32_t i1 = fetch_mask1(inv, g), l1 = fetch_mask1(low, g), c = fetch_code2(codes, g);
+        uint8_t ch;
+        if (i1 && l1) ch = 0;
+        else if (i1) ch = 'N';
+        else ch = uint8_t("ATGC"[c] | (l1 ? 0x20 : 0));
+        out[t] = ch;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase A counting.  Every padded position p contributes exactly ONE histogram update: to the table
+// of order r = min(run, K) at the code of its longest valid word, where run = number of consecutive
+// valid bases starting at p (a PAD or an invalid letter stops it; with --maskHost a soft-masked base
+// stops it too, L336-337).  Lower orders follow by marginalisation (marginalize_kernel): a valid
+// (r)-mer contains a valid x-mer prefix for every x <= r, so
+//      C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b]          (C_K = D_K)
+// which is exact, including scaffold ends and N-adjacent positions.  `raw` = the D tables (profile
+// layout) followed by {totalLen, #K-mer start positions, nnTotal, 0}; everything in it is a plain sum
+// over positions, hence summable across batches and across GPUs.
+// LDS_HIST: when the whole profile fits, privatise it in LDS (u32) and flush once per block.
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_HIST>
+__global__ __launch_bounds__(256) void profile_add_kernel(const uint32_t* __restrict__ codes,
+                                                           const uint32_t* __restrict__ inv,
+                                                           const uint32_t* __restrict__ low, int64_t p0, int64_t p1,
+                                                           int kmin, int kmax, int mask_host, int nprof,
+                                                           unsigned long long* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    if (LDS_HIST) {
+        for (int b = threadIdx.x; b < nprof; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+    }
+    unsigned long long tot = 0, kpos = 0, nn = 0;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t p = p0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < p1; p += stride) {
+        const uint32_t inv8 = fetch_mask8(inv, p), low8 = fetch_mask8(low, p);
+        const uint32_t pad8 = inv8 & low8;
+        const uint32_t real = ((pad8 >> 7) & 1u) ^ 1u;
+        const uint32_t eff = inv8 | (mask_host ? low8 : 0u);
+        int run = lead_clear8(eff);
+        run = run < kmax ? run : kmax;
+        if (run >= kmin) {
+            const uint32_t code = fetch_codes16(codes, p) >> (16 - 2 * run);
+            const int64_t bin = table_offset(kmin, run) + code;
+            if (LDS_HIST) atomicAdd(&hist[bin], 1u);
+            else atomicAdd(&raw[bin], 1ull);
+        }
+        tot += real;
+        nn += real & (((inv8 | low8) >> 7) & 1u);            // not an uppercase A/T/G/C (countN, L106-118)
+        kpos += ((pad8 >> (8 - kmax)) == 0u) ? 1u : 0u;       // a K-mer can start here (L329)
+    }
+    // wave-level reduction of the three scalars, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        tot += __shfl_down(tot, o);
+        kpos += __shfl_down(kpos, o);
+        nn += __shfl_down(nn, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (tot) atomicAdd(&raw[nprof + 0], tot);
+        if (kpos) atomicAdd(&raw[nprof + 1], kpos);
+        if (nn) atomicAdd(&raw[nprof + 2], nn);
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < nprof; b += blockDim.x) {
+            const uint32_t v = hist[b];
+            if (v) atomicAdd(&raw[b], (unsigned long long)v);
+        }
+    }
+}
+
+// C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b], in place on a copy of the D tables; one launch per order,
+// from K-1 down to kmin (4^x threads each).
+__global__ __launch_bounds__(256) void marginalize_kernel(int64_t* __restrict__ cnt, int kmin, int x) {
+    const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= (int64_t(1) << (2 * x))) return;
+    const int64_t* up = cnt + table_offset(kmin, x + 1) + 4 * q;
+    cnt[table_offset(kmin, x) + q] += up[0] + up[1] + up[2] + up[3];
+}
+
+// genome mode adds the reverse complement of every counted word (L350-351):
+// sym[c] = fwd[c] + fwd[rc(c)] - a palindromic word therefore counts twice per occurrence.
+__global__ __launch_bounds__(256) void symmetrize_kernel(const int64_t* __restrict__ fwd, int64_t* __restrict__ sym,
+                                                          int kmin, int kmax) {
+    const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (int x = kmin; x <= kmax; ++x) {
+        const int64_t off = table_offset(kmin, x), n = int64_t(1) << (2 * x);
+        if (t >= off && t < off + n) {
+            const uint32_t c = uint32_t(t - off);
+            sym[t] = fwd[t] + fwd[off + revcomp_code(c, x)];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Genome-side IVOM value of EVERY max-mer, before normalisation (IvomBuild with isGenomeIVOM=True,
+// L411-450).  It depends only on the genome profile, so it is computed once per profile; the scan
+// kernel gathers from it and renormalises over the window's present max-mers (L453-454).
+// A zero running weight or a zero divisor is a ZeroDivisionError in the reference (L437, L416-424):
+// encoded as NaN and reported per window if such a max-mer is present there.
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void genome_ivom_kernel(const int64_t* __restrict__ sym, int kmin, int kmax,
+                                                           int64_t genome_space, double* __restrict__ ig) {
+    const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= (int64_t(1) << (2 * kmax))) return;
+    unsigned long long W = 0;
+    double I = 0.0;
+    bool bad = false;
+    for (int x = kmin; x <= kmax; ++x) {
+        const int64_t c = sym[table_offset(kmin, x) + (k >> (2 * (kmax - x)))];
+        const unsigned long long wt = (unsigned long long)c << (2 * x);
+        W += wt;
+        const int64_t D = (genome_space - (x - 1)) * 2;
+        if (W == 0 || D == 0) { bad = true; break; }
+        const double p = double(c) / double(D);
+        const double a = double(wt) / double(W);
+        I = (x == kmin) ? a * p : a * p + ((1.0 - a) * I);
+    }
+    ig[k] = bad ? __longlong_as_double(0x7FF8000000000000LL) : I;
+}

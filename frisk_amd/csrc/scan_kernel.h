@@ -1,0 +1,424 @@
+// scan_kernel.h - phase B: one launch scores every candidate window of the resident batch.
+//
+// Replaces the reference's per-window loop frisk/__init__.py L1478-1494:
+//   crawlGenome (L194-251) -> computeKmers(window) (L280-367) -> IvomBuild(genome side) + IvomBuild(window
+//   side) (L369-457) -> KLD (L459-472) -> calcGC (L120-137) [-> calcRIP (L474-495)].
+//
+// Mapping onto CDNA4: one 1024-thread workgroup (16 wavefronts) owns one window at a time and keeps the
+// window's k-mer histograms in LDS:
+//   * orders kmin..min(K,7) : dense 16-bit counters (two per LDS dword, updated with 32-bit ds_add)
+//   * order 8 (K = 8)        : dense 16-bit counters, 128 KiB - the reason a workgroup owns a whole CU;
+//                              order 7 is then NOT stored: c7(q) = sum of the four order-8 children of q
+//                              (one 8-byte LDS read) + the few "orphan" 7-mers whose 8th base is missing
+//                              (window tail, or an invalid base), kept in a short LDS list.
+// Each position does one returning LDS atomic on its max-mer; the lane that sees the old value 0 becomes
+// the *representative* of that max-mer and later evaluates its IVOM recursion, so no scan over the 4^K
+// bins is ever needed, and bins are re-zeroed by their representatives instead of a 128 KiB clear.
+// FP64 throughout (the KLD sum cancels from O(1) terms to O(1e-2)); contraction off so that every
+// product/sum rounds exactly as CPython's does.  No MFMA: this is histogramming + a scalar recurrence.
+#pragma once
+#include "frisk_device.h"
+
+#define FRISK_SCAN_NT 1024
+#define FRISK_T8_BYTES 131072
+
+struct ScanParams {
+    const uint32_t* codes;
+    const uint32_t* inv;
+    const uint32_t* low;
+    const ScafDesc* descs;
+    const double* ig;         // genome-side IVOM, 4^kmax entries (NaN = zero weight)
+    int32_t n_desc;
+    int32_t kmin, kmax;
+    int32_t w, inc;
+    uint32_t flags;           // FRISK_SCAN_*
+    int64_t c0, c1;           // candidate range
+    int32_t chunk;            // consecutive candidates handed to a workgroup at a time
+    int32_t orphan_cap;       // capacity of the orphan list (entries)
+    int32_t nprof;            // profile length (debug dump stride)
+    // outputs, indexed by (candidate - c0)
+    int32_t* seq_index;
+    int64_t* start;
+    int64_t* stop;
+    uint32_t* status;
+    double* kld;
+    double* gc;
+    double* pi;
+    double* si;
+    double* cri;
+    uint32_t* dbg_counts;
+    int64_t* dbg_meta;
+};
+
+#define ROW_KEPT 1u
+#define ROW_ZERO_WEIGHT 2u
+#define ROW_JUMPBACK 4u
+#define ROW_NO_MAXMER 8u
+
+#pragma clang fp contract(off)
+
+// LDS carve-up (dynamic, all offsets multiples of 16 bytes)
+struct LdsLayout {
+    uint32_t t8;        // byte offset of the order-8 table (K8 only)
+    uint32_t small;     // byte offset of the small tables (orders kmin..ks), u16 bins
+    uint32_t small_bytes;
+    uint32_t orphans;   // u16 list
+    uint32_t misc;      // counters + reduction scratch
+    uint32_t total;
+};
+
+__host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap) {
+    LdsLayout L;
+    const bool k8 = (kmax == 8);
+    const int ks = k8 ? 6 : kmax;
+    uint32_t o = 0;
+    L.t8 = o;
+    if (k8) o += FRISK_T8_BYTES;
+    L.small = o;
+    int64_t bins = (ks >= kmin) ? table_offset(kmin, ks + 1) : 0;
+    L.small_bytes = uint32_t((bins * 2 + 15) / 16 * 16);
+    o += L.small_bytes;
+    L.orphans = o;
+    o += uint32_t((k8 ? orphan_cap : 0) * 2 + 15) / 16 * 16;
+    L.misc = o;
+    o += 16 * 4 + 2 * 16 * 8 + 16;   // 16 u32 counters, 2 x 16 doubles of reduction scratch
+    L.total = (o + 15) / 16 * 16;
+    return L;
+}
+
+// misc counter slots
+enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS, M_COUNT = 16 };
+
+template <bool K8>
+struct WinTables {
+    uint32_t* t8_32;         // order-8 table as dwords
+    const uint16_t* t8_16;
+    uint32_t* small32;
+    const uint16_t* small16;
+    const uint16_t* orph;
+    int n_orph;
+    int kmin, kmax;
+
+    // count of the x-mer `c` in the current window
+    __device__ inline uint32_t count(int x, uint32_t c) const {
+        if (K8) {
+            if (x == 8) return t8_16[c];
+            if (x == 7) {
+                const uint2 q = *reinterpret_cast<const uint2*>(t8_16 + 4 * c);   // 4 children, 8-byte aligned
+                uint32_t s = (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16);
+                for (int o = 0; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
+                return s;
+            }
+        }
+        return small16[table_offset(kmin, x) + c];
+    }
+};
+
+template <int NW>
+__device__ inline void block_sum2(double& a, double& b, double* scratch, int tid) {
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o);
+        b += __shfl_down(b, o);
+    }
+    __syncthreads();                       // scratch free (previous readers done)
+    if ((tid & 63) == 0) {
+        scratch[tid >> 6] = a;
+        scratch[NW + (tid >> 6)] = b;
+    }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < NW; ++w) {         // fixed order: deterministic, identical in every thread
+        sa += scratch[w];
+        sb += scratch[NW + w];
+    }
+    a = sa;
+    b = sb;
+}
+
+// ITS > 0: windows of at most ITS*NT positions keep their per-representative IVOM values in registers
+// between the two passes; ITS == 0: any length, values are recomputed in pass 2.
+template <bool K8, int ITS, bool DEBUG>
+__global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P) {
+    constexpr int NT = FRISK_SCAN_NT;
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kmin = P.kmin, kmax = P.kmax;
+    const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap);
+    uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L.t8);
+    uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
+    uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L.orphans);
+    uint32_t* misc = reinterpret_cast<uint32_t*>(lds + L.misc);
+    double* scratch = reinterpret_cast<double*>(lds + L.misc + M_COUNT * 4);
+    const int ks = K8 ? 6 : kmax;                       // highest order kept in the small tables
+
+    // one-time clear of the histograms
+    if (K8) for (int i = tid; i < FRISK_T8_BYTES / 16; i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
+    if (tid < M_COUNT) misc[tid] = 0;
+    __syncthreads();
+
+    // XCD-aware work split: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+    // contiguous run of chunk ids - neighbouring windows overlap by w-inc bases and then share one L2.
+    const int G = gridDim.x;
+    int v = blockIdx.x;
+    if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int64_t ncand = P.c1 - P.c0;
+    const int64_t nchunks = (ncand + P.chunk - 1) / P.chunk;
+
+    ScafDesc d;
+    d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
+    int dsi = -1;
+
+    for (int64_t q = v; q < nchunks; q += G) {
+        const int64_t cb = P.c0 + q * P.chunk;
+        const int64_t ce = (cb + P.chunk < P.c1) ? cb + P.chunk : P.c1;
+        for (int64_t cand = cb; cand < ce; ++cand) {
+            // ---- which scaffold / window is this candidate? (uniform across the workgroup)
+            if (cand < d.cand0 || cand >= d.cand0 + d.ncand) {
+                int lo = 0, hi = P.n_desc - 1;          // last descriptor with cand0 <= cand and ncand > 0
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (P.descs[mid].cand0 <= cand) lo = mid; else hi = mid - 1;
+                }
+                // (descriptors without candidates share cand0 with their successor, so the LAST
+                //  descriptor with cand0 <= cand is always the one that owns the candidate)
+                d = P.descs[lo];
+                dsi = lo;
+            }
+            const int64_t j = cand - d.cand0;
+            int64_t st;                // 0-based first base of the window inside the scaffold
+            int64_t rep_start, rep_stop;   // coordinates as the reference reports them
+            int n;
+            bool jump = false;
+            if (d.kind == 1) { st = 0; n = int(d.size); rep_start = 1; rep_stop = d.size; }      // L219
+            else {
+                st = j * P.inc;
+                n = P.w;
+                rep_start = st + 1; rep_stop = st + P.w;                                        // L245
+                if (st + P.w > d.size) {                                                        // L230-232
+                    jump = true;
+                    st = d.size - P.w;
+                    rep_start = st; rep_stop = d.size;                                          // L243: 0-based start
+                    // a scaffold shorter than w: seq[size-w:size] with a negative start is a Python slice
+                    // counted from the end, clamped at 0
+                    if (st < 0) { st += d.size; if (st < 0) st = 0; }
+                    n = int(d.size - st);
+                }
+            }
+            const int64_t g0 = d.off + st;
+            const int64_t row = cand - P.c0;
+
+            // ---- phase 0: uppercase base composition (calcGC L120-137, countN L106-118) -------------
+            {
+                uint32_t cA = 0, cT = 0, cG = 0, cC = 0;
+                for (int jj = tid; jj - lane < n; jj += NT) {
+                    bool up = false;
+                    uint32_t c2 = 0;
+                    if (jj < n) {
+                        const int64_t g = g0 + jj;
+                        up = !(fetch_mask1(P.inv, g) | fetch_mask1(P.low, g));
+                        c2 = fetch_code2(P.codes, g);
+                    }
+                    cA += __popcll(__ballot(up && c2 == 0));
+                    cT += __popcll(__ballot(up && c2 == 1));
+                    cG += __popcll(__ballot(up && c2 == 2));
+                    cC += __popcll(__ballot(up && c2 == 3));
+                }
+                if (lane == 0) {
+                    if (cA) atomicAdd(&misc[M_UPA], cA);
+                    if (cT) atomicAdd(&misc[M_UPT], cT);
+                    if (cG) atomicAdd(&misc[M_UPG], cG);
+                    if (cC) atomicAdd(&misc[M_UPC], cC);
+                }
+            }
+            __syncthreads();
+            const uint32_t upA = misc[M_UPA], upT = misc[M_UPT], upG = misc[M_UPG], upC = misc[M_UPC];
+            const int64_t S = int64_t(upA) + upT + upG + upC;       // windowSpace (L380)
+            const int64_t nn = n - S;                               // nnTotal of the window
+            // N filter (L237-241 / L213): dropped when nn >= 0.3 * len, evaluated in double like CPython
+            const bool keep = !(double(nn) >= 0.3 * double(n));
+            uint32_t status = (jump ? ROW_JUMPBACK : 0u);
+            if (tid == 0) {
+                P.seq_index[row] = dsi;
+                P.start[row] = rep_start;
+                P.stop[row] = rep_stop;
+            }
+            if (!keep) {
+                __syncthreads();                    // everyone has read misc
+                if (tid < 4) misc[tid] = 0;
+                if (tid == 0) {
+                    P.status[row] = status;
+                    const double qnan = __longlong_as_double(0x7FF8000000000000LL);
+                    P.kld[row] = qnan; P.gc[row] = qnan;
+                    if (P.flags & 1u) { P.pi[row] = qnan; P.si[row] = qnan; P.cri[row] = qnan; }
+                }
+                __syncthreads();
+                continue;
+            }
+
+            // ---- phase 1: histogram every order; elect one representative per present max-mer --------
+            unsigned long long repmask = 0;
+            {
+                uint32_t nvalid = 0;
+                int it = 0;
+                for (int jj = tid; jj - lane < n; jj += NT, ++it) {
+                    bool is_top = false;
+                    if (jj < n) {
+                        const int64_t g = g0 + jj;
+                        const uint32_t c16 = fetch_codes16(P.codes, g);
+                        int run = lead_clear8(fetch_mask8(P.inv, g));       // window words are upper-cased: L334-335
+                        const int rem = n - jj;
+                        run = run < rem ? run : rem;
+                        run = run < kmax ? run : kmax;
+                        const int xs = run < ks ? run : ks;
+                        for (int x = kmin; x <= xs; ++x) {
+                            if (!K8 && x == kmax) break;                   // the top order is handled below
+                            const uint32_t b = uint32_t(table_offset(kmin, x)) + (c16 >> (16 - 2 * x));
+                            atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                        }
+                        if (K8) {
+                            if (run == 8) {
+                                const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
+                                is_top = true;
+                                if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                            } else if (run == 7 && kmin <= 7) {
+                                const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
+                                orph[slot] = uint16_t(c16 >> 2);
+                            }
+                        } else if (run == kmax) {
+                            const uint32_t b = uint32_t(table_offset(kmin, kmax)) + (c16 >> (16 - 2 * kmax));
+                            const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                            is_top = true;
+                            if (((old >> ((b & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                        }
+                    }
+                    nvalid += __popcll(__ballot(is_top));
+                }
+                if (lane == 0 && nvalid) atomicAdd(&misc[M_NVALID], nvalid);
+            }
+            __syncthreads();
+
+            WinTables<K8> T;
+            T.t8_32 = t8; T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
+            T.small32 = small32; T.small16 = reinterpret_cast<const uint16_t*>(small32);
+            T.orph = orph; T.n_orph = K8 ? int(misc[M_NORPH]) : 0;
+            T.kmin = kmin; T.kmax = kmax;
+            const uint32_t nvalid_top = misc[M_NVALID];
+
+            if (DEBUG && P.dbg_counts) {
+                uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
+                for (int x = kmin; x <= kmax; ++x) {
+                    const int64_t off = table_offset(kmin, x);
+                    for (uint32_t c = tid; c < (1u << (2 * x)); c += NT) out[off + c] = T.count(x, c);
+                }
+            }
+            if (DEBUG && P.dbg_meta && tid == 0) {
+                P.dbg_meta[row * 3 + 0] = n;                                                   // totalLen
+                P.dbg_meta[row * 3 + 1] = (n >= kmax ? n - kmax + 1 : 0) - int64_t(nvalid_top); // exMax (L344-345)
+                P.dbg_meta[row * 3 + 2] = nn;                                                  // nnTotal
+            }
+
+            // ---- phase 2: IVOM of every present max-mer, window side (L394-450) and genome side (table) --
+            double iw_keep[ITS > 0 ? ITS : 1], ig_keep[ITS > 0 ? ITS : 1];
+            double Sw = 0.0, Sg = 0.0;
+            bool zero_w = false;
+            auto window_ivom = [&](uint32_t code) -> double {
+                unsigned long long W = 0;
+                double I = 0.0;
+                for (int x = kmin; x <= kmax; ++x) {
+                    const uint32_t cx = T.count(x, code >> (2 * (kmax - x)));
+                    const unsigned long long wt = (unsigned long long)cx << (2 * x);    // count * 4**x (L399-408)
+                    W += wt;
+                    const double p = double(cx) / double((S - (x - 1)) * 2);           // L401-409
+                    const double a = double(wt) / double(W);                            // L437
+                    I = (x == kmin) ? a * p : a * p + ((1.0 - a) * I);                  // L442-446
+                }
+                return I;
+            };
+            auto code_at = [&](int it) -> uint32_t {
+                return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT) >> (16 - 2 * kmax);
+            };
+            if (ITS > 0) {
+#pragma unroll
+                for (int it = 0; it < ITS; ++it) {
+                    iw_keep[it] = 0.0; ig_keep[it] = 0.0;
+                    if ((repmask >> it) & 1ull) {
+                        const uint32_t code = code_at(it);
+                        const double Iw = window_ivom(code);
+                        const double Ig = P.ig[code];
+                        zero_w |= (Ig != Ig);
+                        iw_keep[it] = Iw; ig_keep[it] = Ig;
+                        Sw += Iw; Sg += Ig;
+                    }
+                }
+            } else {
+                for (int it = 0; it * NT < n; ++it) {
+                    if ((repmask >> it) & 1ull) {
+                        const uint32_t code = code_at(it);
+                        const double Iw = window_ivom(code);
+                        const double Ig = P.ig[code];
+                        zero_w |= (Ig != Ig);
+                        Sw += Iw; Sg += Ig;
+                    }
+                }
+            }
+            if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
+            block_sum2<NW>(Sw, Sg, scratch, tid);           // sumWindowIVOM of both sides (L450)
+
+            // ---- phase 3: normalise (L453-454) and accumulate the divergence (L465-470) ----------------
+            double acc = 0.0, unused = 0.0;
+            const double LN2 = 0.69314718055994530942;      // math.log(x, 2) == log(x) / log(2.0)
+            auto term = [&](double Iw, double Ig) -> double {
+                const double pw = Iw / Sw;
+                const double pg = Ig / Sg;
+                return (pg != 0.0) ? pw * (log(pw / pg) / LN2) : 0.0;
+            };
+            if (ITS > 0) {
+#pragma unroll
+                for (int it = 0; it < ITS; ++it)
+                    if ((repmask >> it) & 1ull) acc += term(iw_keep[it], ig_keep[it]);
+            } else {
+                for (int it = 0; it * NT < n; ++it)
+                    if ((repmask >> it) & 1ull) {
+                        const uint32_t code = code_at(it);
+                        acc += term(window_ivom(code), P.ig[code]);
+                    }
+            }
+            block_sum2<NW>(acc, unused, scratch, tid);
+            const uint32_t flags_lds = misc[M_FLAGS];
+
+            // RIP indices from the window's dinucleotide counts (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3
+            double pi = 0, si = 0, cri = 0;
+            if ((P.flags & 1u) && tid == 0) {
+                const double qnan = __longlong_as_double(0x7FF8000000000000LL);
+                const uint32_t AT = T.count(2, 1), TA = T.count(2, 4), TG = T.count(2, 6), GT = T.count(2, 9),
+                               CA = T.count(2, 12), AC = T.count(2, 3);
+                pi = AT > 0 ? double(TA) / double(AT) : qnan;
+                si = (AC + GT) > 0 ? double(CA + TG) / double(AC + GT) : qnan;
+                cri = (pi == 0.0 || si == 0.0) ? qnan : pi - si;        // "if PI and SI" (L491): 0.0 is falsy
+            }
+            __syncthreads();            // all reads of the tables are done
+
+            // ---- clean up: representatives zero their max-mer bin; small tables cleared wholesale ----------
+            if (K8) {
+                for (int it = 0; it * NT < n; ++it)
+                    if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code_at(it)] = 0;
+            }
+            for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
+            if (tid < M_COUNT) misc[tid] = 0;
+            if (tid == 0) {
+                if (nvalid_top == 0) status |= ROW_NO_MAXMER;
+                // a zero divisor on the window side (L401-409) needs windowSpace in [kmin-1, kmax-1]
+                if (nvalid_top > 0 && S >= kmin - 1 && S <= kmax - 1) status |= ROW_ZERO_WEIGHT;
+                status |= ROW_KEPT | (flags_lds & ROW_ZERO_WEIGHT);
+                P.status[row] = status;
+                P.kld[row] = acc;
+                P.gc[row] = double(upG + upC) / double(S);              // L136
+                if (P.flags & 1u) { P.pi[row] = pi; P.si[row] = si; P.cri[row] = cri; }
+            }
+            __syncthreads();
+        }
+    }
+}

@@ -1,0 +1,89 @@
+// synth_kernel.h - synthetic scaffolds generated on the device (bench / property tests).
+//
+// "Synthetic scaffolds of the named shape" (BASELINE.json): order-3 Markov background, compositional
+// islands drawn from a second, more skewed table, runs of N at two scales and soft-masked runs.  Every
+// property of a base is a pure function of (seed, scaffold index, position), so generation is parallel
+// over 4096-base blocks and frisk_amd/synth.py reproduces the same bytes on the host with numpy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SYNTH_BLOCK 4096
+#define SYNTH_ISLAND_BLOCKS 5      // island decision per 5 blocks  (20 480 bases)
+#define SYNTH_NBIG_BLOCKS 8        // large N runs: units of 8 blocks (32 768 bases)
+#define SYNTH_NSMALL 1024          // small N runs: units of 1 024 bases
+#define SYNTH_LOWER 512            // soft-masked runs: units of 512 bases
+#define SYNTH_GOLDEN 0x9E3779B97F4A7C15ull
+
+struct SynthTables {
+    uint32_t bg[64][4];            // cumulative 32-bit thresholds per order-3 context
+    uint32_t isl[64][4];
+};
+
+__host__ __device__ inline uint64_t synth_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__host__ __device__ inline uint32_t synth_unit_hash(uint64_t seed, uint32_t scaf, uint64_t unit, uint64_t salt) {
+    return uint32_t(synth_mix(seed ^ synth_mix((uint64_t(scaf) << 40) ^ unit ^ (salt << 56))) >> 32);
+}
+
+inline uint32_t synth_frac_to_u32(double f) {
+    if (!(f > 0.0)) return 0u;
+    if (f >= 1.0) return 0xFFFFFFFFu;
+    return uint32_t(f * 4294967296.0);
+}
+
+inline void synth_make_tables(uint64_t seed, SynthTables& T) {
+    for (int ctx = 0; ctx < 64; ++ctx) {
+        uint64_t wb[4], wi[4], tb = 0, ti = 0;
+        for (int b = 0; b < 4; ++b) {
+            const uint64_t h = synth_mix(seed ^ synth_mix(0xB5ull + uint64_t(ctx) * 4 + uint64_t(b)));
+            wb[b] = 64 + (h % 192);                 // background: mild skew (<= 4:1)
+            wi[b] = 16 + ((h >> 20) % 1009);        // islands: strong skew
+            tb += wb[b];
+            ti += wi[b];
+        }
+        uint64_t cb = 0, ci = 0;
+        for (int b = 0; b < 4; ++b) {
+            cb += wb[b];
+            ci += wi[b];
+            T.bg[ctx][b] = (b == 3) ? 0xFFFFFFFFu : uint32_t((cb << 32) / tb);
+            T.isl[ctx][b] = (b == 3) ? 0xFFFFFFFFu : uint32_t((ci << 32) / ti);
+        }
+    }
+}
+
+// one thread per 4096-base block of one scaffold
+__global__ __launch_bounds__(64) void synth_kernel(uint8_t* __restrict__ out, int64_t len, uint64_t seed, uint32_t scaf,
+                                                    const SynthTables T, uint32_t thr_island, uint32_t thr_nbig,
+                                                    uint32_t thr_nsmall, uint32_t thr_low) {
+    const int64_t nblk = (len + SYNTH_BLOCK - 1) / SYNTH_BLOCK;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t blk = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; blk < nblk; blk += stride) {
+        const bool island = synth_unit_hash(seed, scaf, uint64_t(blk / SYNTH_ISLAND_BLOCKS), 1) < thr_island;
+        const bool nbig = synth_unit_hash(seed, scaf, uint64_t(blk / SYNTH_NBIG_BLOCKS), 2) < thr_nbig;
+        uint64_t state = synth_mix(seed ^ synth_mix((uint64_t(scaf) << 40) ^ uint64_t(blk)));
+        uint32_t ctx = 0;
+        const int64_t base = blk * SYNTH_BLOCK;
+        const int64_t end = (base + SYNTH_BLOCK < len) ? base + SYNTH_BLOCK : len;
+        bool nsmall = false, lowr = false;
+        for (int64_t p = base; p < end; ++p) {
+            if ((p & (SYNTH_LOWER - 1)) == 0 || p == base) {
+                nsmall = synth_unit_hash(seed, scaf, uint64_t(p / SYNTH_NSMALL), 3) < thr_nsmall;
+                lowr = synth_unit_hash(seed, scaf, uint64_t(p / SYNTH_LOWER), 4) < thr_low;
+            }
+            state += SYNTH_GOLDEN;
+            const uint32_t r = uint32_t(synth_mix(state) >> 32);
+            const uint32_t* row = island ? T.isl[ctx] : T.bg[ctx];
+            const uint32_t b = (r >= row[0]) + (r >= row[1]) + (r >= row[2]);
+            ctx = ((ctx << 2) | b) & 63u;
+            uint8_t ch = uint8_t("ATGC"[b]);
+            if (lowr) ch |= 0x20;
+            if (nbig || nsmall) ch = 'N';
+            out[p] = ch;
+        }
+    }
+}

@@ -1,0 +1,198 @@
+"""Engine: one libfrisk_hip context (one GPU, one HIP stream) with numpy in / numpy out.
+
+Thin host plumbing over the C ABI (include/frisk_hip.h); all arithmetic of the hot path runs in
+the HIP kernels.  torch is used only by `profile_allreduce` (RCCL through torch.distributed).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+def profile_len(kmin, kmax):
+    return sum(4 ** x for x in range(kmin, kmax + 1))
+
+
+def table_offset(kmin, x):
+    return (4 ** x - 4 ** kmin) // 3
+
+
+class ScanResult:
+    """Per-candidate arrays of one frisk_scan call; `kept` selects the rows the reference emits."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @property
+    def kept(self):
+        return (self.status & _ffi.ROW_KEPT) != 0
+
+    @property
+    def zero_weight(self):
+        return (self.status & _ffi.ROW_ZERO_WEIGHT) != 0
+
+    def __len__(self):
+        return int(self.status.shape[0])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    def __init__(self, kmin, kmax, device=0):
+        self._lib = _ffi.lib()
+        self._ctx = C.c_void_p()
+        self.kmin, self.kmax, self.device = int(kmin), int(kmax), int(device)
+        rc = self._lib.frisk_create(self.device, self.kmin, self.kmax, C.byref(self._ctx))
+        if rc != _ffi.OK:
+            msg = self._lib.frisk_last_error(self._ctx).decode() if self._ctx else "allocation failed"
+            if self._ctx:
+                self._lib.frisk_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise _ffi.FriskHipError(rc, msg)
+        self.nprof = int(self._lib.frisk_profile_len(self._ctx))
+        self.n_seq = 0
+        self.seq_lens = []
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.frisk_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != _ffi.OK:
+            raise _ffi.FriskHipError(rc, self._lib.frisk_last_error(self._ctx).decode())
+
+    # ----------------------------------------------------------------- sequences
+    def load(self, seqs):
+        """Make a batch of scaffolds resident (list of bytes / str / uint8 arrays)."""
+        bufs = []
+        for s in seqs:
+            if isinstance(s, str):
+                s = s.encode("ascii")
+            elif isinstance(s, np.ndarray):
+                s = s.astype(np.uint8, copy=False).tobytes()
+            bufs.append(bytes(s))
+        n = len(bufs)
+        arr = (C.c_char_p * max(n, 1))(*bufs)
+        lens = (C.c_int64 * max(n, 1))(*[len(b) for b in bufs])
+        self._check(self._lib.frisk_seq_load(self._ctx, arr, lens, n))
+        self.n_seq = n
+        self.seq_lens = [len(b) for b in bufs]
+
+    def synth(self, lens, seed, island_frac=0.02, n_frac=0.0, lower_frac=0.0):
+        lens = [int(x) for x in lens]
+        arr = (C.c_int64 * max(len(lens), 1))(*lens)
+        self._check(self._lib.frisk_seq_synth(self._ctx, arr, len(lens), C.c_uint64(seed), float(island_frac),
+                                              float(n_frac), float(lower_frac)))
+        self.n_seq = len(lens)
+        self.seq_lens = lens
+
+    def read_seq(self, index):
+        n = self.seq_lens[index]
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        self._check(self._lib.frisk_seq_read(self._ctx, index, _ptr(out), n))
+        return out[:n].tobytes()
+
+    @property
+    def padded_len(self):
+        return int(self._lib.frisk_seq_padded_len(self._ctx))
+
+    # ------------------------------------------------------------------- phase A
+    def profile_reset(self):
+        self._check(self._lib.frisk_profile_reset(self._ctx))
+
+    def profile_add(self, mask_host=False, pos_begin=-1, pos_end=-1):
+        self._check(self._lib.frisk_profile_add(self._ctx, 1 if mask_host else 0, pos_begin, pos_end))
+
+    def profile_raw(self):
+        out = np.empty(self.nprof + 4, dtype=np.int64)
+        self._check(self._lib.frisk_profile_export_host(self._ctx, _ptr(out)))
+        return out
+
+    def profile_set_raw(self, raw):
+        raw = np.ascontiguousarray(raw, dtype=np.int64)
+        assert raw.shape == (self.nprof + 4,)
+        self._check(self._lib.frisk_profile_import_host(self._ctx, _ptr(raw)))
+
+    def profile_allreduce(self, group=None):
+        """Sum the raw (linear) profile over all ranks: ONE all-reduce (RCCL when the process group's
+        backend is nccl; gloo works too for the CPU rehearsal of the multi-rank path)."""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        n = self.nprof + 4
+        if dist.get_backend(group) == "nccl":
+            t = torch.empty(n, dtype=torch.int64, device="cuda:%d" % self.device)
+            self._check(self._lib.frisk_profile_export_device(self._ctx, C.c_void_p(t.data_ptr())))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(t.device)
+            self._check(self._lib.frisk_profile_import_device(self._ctx, C.c_void_p(t.data_ptr())))
+        else:
+            t = torch.from_numpy(self.profile_raw())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            self.profile_set_raw(t.numpy())
+
+    def profile_finalize(self):
+        self._check(self._lib.frisk_profile_finalize(self._ctx))
+
+    def profile_get(self):
+        sym = np.empty(self.nprof, dtype=np.int64)
+        tl, ex, nn = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.frisk_profile_get(self._ctx, _ptr(sym), C.byref(tl), C.byref(ex), C.byref(nn)))
+        return sym, int(tl.value), int(ex.value), int(nn.value)
+
+    def profile_set(self, sym, total_len, ex_max, nn_total):
+        sym = np.ascontiguousarray(sym, dtype=np.int64)
+        assert sym.shape == (self.nprof,)
+        self._check(self._lib.frisk_profile_set(self._ctx, _ptr(sym), int(total_len), int(ex_max), int(nn_total)))
+
+    # ------------------------------------------------------------------- phase B
+    def scan_plan(self, w, inc, scaffolds_all=False):
+        n = C.c_int64()
+        flags = _ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0
+        self._check(self._lib.frisk_scan_plan(self._ctx, int(w), int(inc), flags, C.byref(n)))
+        return int(n.value)
+
+    def scan(self, w, inc, rip=False, scaffolds_all=False, c0=0, c1=-1, debug=False):
+        flags = (_ffi.SCAN_RIP if rip else 0) | (_ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0)
+        total = self.scan_plan(w, inc, scaffolds_all)
+        if c1 < 0:
+            c1 = total
+        n = max(c1 - c0, 0)
+        cap = max(n, 1)
+        r = ScanResult(
+            seq_index=np.zeros(cap, np.int32), start=np.zeros(cap, np.int64), stop=np.zeros(cap, np.int64),
+            status=np.zeros(cap, np.uint32), kld=np.zeros(cap, np.float64), gc=np.zeros(cap, np.float64),
+            pi=np.zeros(cap, np.float64) if rip else None, si=np.zeros(cap, np.float64) if rip else None,
+            cri=np.zeros(cap, np.float64) if rip else None,
+            counts=np.zeros((cap, self.nprof), np.uint32) if debug else None,
+            meta=np.zeros((cap, 3), np.int64) if debug else None)
+        self._check(self._lib.frisk_scan(self._ctx, int(w), int(inc), flags, int(c0), int(c1), cap,
+                                         _ptr(r.seq_index), _ptr(r.start), _ptr(r.stop), _ptr(r.status),
+                                         _ptr(r.kld), _ptr(r.gc), _ptr(r.pi), _ptr(r.si), _ptr(r.cri),
+                                         _ptr(r.counts), _ptr(r.meta)))
+        for k, v in list(r.__dict__.items()):
+            if isinstance(v, np.ndarray):
+                setattr(r, k, v[:n])
+        r.n_candidates = total
+        return r
+
+    def kernel_ms(self, which=0):
+        return float(self._lib.frisk_last_kernel_ms(self._ctx, which))

@@ -1,0 +1,116 @@
+"""Host-side mirror of the reference's hot-path call pattern, running on the GPU.
+
+The reference (frisk/__init__.py) drives the path from main():
+    L1442        genomeKmers = computeKmers(args, genomeMode=True, ...)            phase A
+    L1478-1494   for seq, name, start, stop in crawlGenome(args, querySeq): ...     phase B
+Here the same two seams are `genomeProfile(args)` and `scanGenome(args, querySeq, genomeKmers)`;
+both take the same argparse-style `args` object (hostSeq, minWordSize, maxWordSize, windowlen,
+increment, maskHost, scaffoldsAll, RIP) and produce the same values: the list-of-dicts k-mer maps
+with the three metadata dicts appended (L356-359), and rows (name, start, stop, windowKLD, GC[, PI,
+SI, CRI]) in the reference's order.  Where the reference would die with ZeroDivisionError
+(L437: a window max-mer whose prefix has zero weight in the genome) scanGenome raises it too.
+"""
+import numpy as np
+
+from . import _ffi
+from .engine import Engine, table_offset
+from .fasta import readFasta
+
+LETTERS = ("A", "T", "G", "C")      # reference L70
+
+
+def kmerString(code, x):
+    return "".join(LETTERS[(code >> (2 * (x - 1 - p))) & 3] for p in range(x))
+
+
+def rangeMaps(kMin, kMax):
+    """Blank maps: one dict per order, keys in canonical index order (reference L253-274)."""
+    return [{kmerString(c, x): 0 for c in range(4 ** x)} for x in range(kMin, kMax + 1)]
+
+
+def profileToMaps(sym, total_len, ex_max, nn_total, kMin, kMax):
+    """flat symmetric counts -> the reference's pickled structure (L356-359)."""
+    maps = []
+    for x in range(kMin, kMax + 1):
+        off = table_offset(kMin, x)
+        vals = sym[off:off + 4 ** x].tolist()
+        maps.append({kmerString(c, x): vals[c] for c in range(4 ** x)})
+    maps.append({"totalLen": int(total_len)})
+    maps.append({"exMax": int(ex_max)})
+    maps.append({"nnTotal": int(nn_total)})
+    return maps
+
+
+def mapsToProfile(maps, kMin, kMax):
+    flat = []
+    for x in range(kMin, kMax + 1):
+        d = maps[x - kMin]
+        flat.extend(d[kmerString(c, x)] for c in range(4 ** x))
+    r = kMax - kMin
+    return (np.asarray(flat, dtype=np.int64), maps[r + 1]["totalLen"], maps[r + 2]["exMax"], maps[r + 3]["nnTotal"])
+
+
+class HotPath:
+    """Owns the Engine and the resident batch for one run of the CLI / one test."""
+
+    def __init__(self, kMin, kMax, device=0):
+        self.engine = Engine(kMin, kMax, device)
+        self.kMin, self.kMax = kMin, kMax
+        self._resident = None       # path of the FASTA whose scaffolds are on the device
+        self.names = []
+
+    def close(self):
+        self.engine.close()
+
+    def _load(self, path):
+        if self._resident != path:
+            self.names, seqs = readFasta(path)
+            self.engine.load(seqs)
+            self._resident = path
+
+    # phase A -----------------------------------------------------------------------------------
+    def genomeProfile(self, args, allreduce=False):
+        """computeKmers(genomeMode=True) (L280-367 as called at L1442)."""
+        self._load(args.hostSeq)
+        e = self.engine
+        e.profile_reset()
+        e.profile_add(mask_host=bool(getattr(args, "maskHost", False)))
+        if allreduce:
+            e.profile_allreduce()
+        e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        return profileToMaps(sym, tl, ex, nn, self.kMin, self.kMax)
+
+    def setGenomeProfile(self, genomeKmers):
+        """Install a previously computed profile (replaces pickle.load at L1437-1439)."""
+        sym, tl, ex, nn = mapsToProfile(genomeKmers, self.kMin, self.kMax)
+        self.engine.profile_set(sym, tl, ex, nn)
+
+    # phase B -----------------------------------------------------------------------------------
+    def scanGenome(self, args, querySeq, debug=False):
+        """The loop L1478-1494.  Returns (rows, result): rows = list of tuples in output order."""
+        self._load(querySeq)
+        rip = bool(getattr(args, "RIP", False)) and args.minWordSize <= 2
+        if rip and args.maxWordSize < 2:
+            raise ValueError("2 is not in list")        # range(m, K+1).index(2), reference L478
+        res = self.engine.scan(args.windowlen, args.increment, rip=rip,
+                               scaffolds_all=bool(getattr(args, "scaffoldsAll", False)), debug=debug)
+        kept = np.nonzero(res.kept)[0]
+        bad = kept[(res.status[kept] & _ffi.ROW_ZERO_WEIGHT) != 0]
+        rows = []
+        stop_at = int(bad[0]) if bad.size else None
+        for r in kept.tolist():
+            if stop_at is not None and r >= stop_at:
+                break
+            name = self.names[int(res.seq_index[r])]
+            kld = 0 if (res.status[r] & _ffi.ROW_NO_MAXMER) else float(res.kld[r])   # int 0: empty sum, L465
+            row = (name, int(res.start[r]), int(res.stop[r]), kld, float(res.gc[r]))
+            if rip:
+                row += (float(res.pi[r]), float(res.si[r]), float(res.cri[r]))
+            rows.append(row)
+        if stop_at is not None and not getattr(args, "tolerateZeroWeight", False):
+            err = ZeroDivisionError("float division by zero")   # what the reference raises at L437
+            err.rows = rows
+            err.result = res
+            raise err
+        return rows, res

@@ -1,0 +1,123 @@
+/* frisk_hip.h - C ABI of libfrisk_hip.so: the MI355X (gfx950) implementation of frisk's hot path.
+ *
+ * The reference (Adamtaranto/frisk, one Python-2 module) has no FFI, plugin or operator
+ * interface; its only stable boundary is the call pattern inside main().  Each entry point
+ * below names the reference lines it replaces (citations are to /root/reference/frisk/__init__.py):
+ *
+ *   phase A  genome k-mer profile      computeKmers(genomeMode=True)   L1442  (L280-367)
+ *   phase B  window scan               the loop L1478-1494: crawlGenome (L194-251) ->
+ *            computeKmers(window) (L280-367) -> IvomBuild x2 (L369-457) -> KLD (L459-472)
+ *            -> calcGC (L120-137) [-> calcRIP (L474-495)]
+ *
+ * Conventions: plain C, plain pointers and sizes, no exceptions, no torch types.  Every
+ * function returning int returns FRISK_OK (0) or a negative FRISK_E_* code; the message is
+ * available from frisk_last_error().  The caller owns every host buffer it passes; the
+ * library never keeps a caller pointer after the call returns.  A context is bound to one
+ * device and one HIP stream and is not thread-safe; use one context per device per thread
+ * (multi-GPU = one process per GPU, one context each).  K-mer index convention (reference
+ * L70, L253-274): digits A=0,T=1,G=2,C=3, first base most significant; tables for orders
+ * kmin..kmax are concatenated in ascending order ("profile layout", frisk_profile_len()).
+ */
+#ifndef FRISK_HIP_H
+#define FRISK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct frisk_ctx frisk_ctx;
+
+enum {
+    FRISK_OK = 0,
+    FRISK_E_ARG = -1,         /* bad argument / unsupported geometry                                   */
+    FRISK_E_HIP = -2,         /* a HIP runtime call failed (no device, out of memory, launch failure)  */
+    FRISK_E_STATE = -3,       /* call order violated (e.g. scan before a profile is finalised)         */
+    FRISK_E_CAP = -4,         /* caller buffer too small; the needed size is reported                  */
+    FRISK_E_ZERO_WEIGHT = -5  /* the reference would raise ZeroDivisionError (L437 / L401-424)         */
+};
+
+/* frisk_scan flags */
+#define FRISK_SCAN_RIP           1u   /* fill pi/si/cri (--RIP, L1485-1486); needs kmin <= 2 <= kmax  */
+#define FRISK_SCAN_SCAFFOLDS_ALL 2u   /* --scaffoldsAll: small scaffolds become one window (L211-221) */
+
+/* per-row status bits written to `status` by frisk_scan */
+#define FRISK_ROW_KEPT        1u      /* window passed the < 30 % non-ACGT filter (L237-241)          */
+#define FRISK_ROW_ZERO_WEIGHT 2u      /* reference raises ZeroDivisionError for this window           */
+#define FRISK_ROW_JUMPBACK    4u      /* end-of-scaffold "jumpback" window (0-based start, L230-243)  */
+
+const char* frisk_version(void);
+
+/* Library limits for (kmin,kmax,window length); 0 = unsupported.  kmax <= 8, window <= 65535. */
+int frisk_supported(int kmin, int kmax, int64_t max_window);
+
+/* Context: device ordinal, word sizes -m/-k (L1197-1206). */
+int  frisk_create(int device, int kmin, int kmax, frisk_ctx** out);
+void frisk_destroy(frisk_ctx* ctx);
+const char* frisk_last_error(const frisk_ctx* ctx);   /* library-owned, valid until the next call on ctx */
+int64_t frisk_profile_len(const frisk_ctx* ctx);      /* sum_{x=kmin..kmax} 4^x                          */
+
+/* ---- sequence residency ------------------------------------------------------------------
+ * Replaces the hand-off of scaffold strings from iterFasta (L139-164) to the counters
+ * (L297, L203).  Uploads n_seq scaffolds (ASCII, any case, any IUPAC letter), packs them on
+ * the device to 2 bits/base + validity and soft-mask bitmaps, and keeps them resident until the
+ * next load.  Empty scaffolds (len 0) are allowed. */
+int frisk_seq_load(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq);
+
+/* Bench/test utility: fill the resident batch with synthetic scaffolds generated ON the device
+ * (order-3 Markov background + compositional islands + N runs + soft-masked runs; the generator
+ * is specified in frisk_amd/synth.py, which reproduces it bit-for-bit on the host). */
+int frisk_seq_synth(frisk_ctx* ctx, const int64_t* lens, int32_t n_seq, uint64_t seed,
+                    double island_frac, double n_frac, double lower_frac);
+
+/* Copy the resident batch back as ASCII (canonical letters: A/T/G/C, a/t/g/c, N) - test utility. */
+int frisk_seq_read(frisk_ctx* ctx, int32_t seq_index, uint8_t* out, int64_t cap);
+
+/* ---- phase A: genome profile (computeKmers genomeMode=True, L1442) -------------------------
+ * reset -> add (once per resident batch; forward counts only) -> [all-reduce across GPUs]
+ * -> finalize (adds the reverse complement, L350-351, and builds the genome-side IVOM table). */
+int frisk_profile_reset(frisk_ctx* ctx);
+/* Count the k-mers that START in padded positions [pos_begin,pos_end) of the resident batch;
+ * pos_begin = pos_end = -1 means the whole batch.  mask_host: --maskHost (L336-337). */
+int frisk_profile_add(frisk_ctx* ctx, int mask_host, int64_t pos_begin, int64_t pos_end);
+int64_t frisk_seq_padded_len(const frisk_ctx* ctx);
+/* Raw (linear, summable) profile state: int64[frisk_profile_raw_len()] on the device.  To
+ * all-reduce across GPUs the caller exports it into its own device buffer (e.g. a torch
+ * tensor), runs ONE RCCL all-reduce(sum) on that, and imports the result. */
+int64_t frisk_profile_raw_len(const frisk_ctx* ctx);
+int frisk_profile_export_device(frisk_ctx* ctx, void* dst_device_int64);
+int frisk_profile_import_device(frisk_ctx* ctx, const void* src_device_int64);
+int frisk_profile_export_host(frisk_ctx* ctx, int64_t* dst_host);
+int frisk_profile_import_host(frisk_ctx* ctx, const int64_t* src_host);
+int frisk_profile_finalize(frisk_ctx* ctx);
+/* The finished profile in the reference's terms: symmetric counts in profile layout and the
+ * three metadata values of L356-359.  Any output pointer may be NULL. */
+int frisk_profile_get(frisk_ctx* ctx, int64_t* sym_counts, int64_t* total_len, int64_t* ex_max,
+                      int64_t* nn_total);
+/* Install a finished profile (e.g. from a cache file; replaces pickle.load at L1437-1439). */
+int frisk_profile_set(frisk_ctx* ctx, const int64_t* sym_counts, int64_t total_len, int64_t ex_max,
+                      int64_t nn_total);
+
+/* ---- phase B: window scan (loop L1478-1494) -------------------------------------------------
+ * Candidate windows of the resident batch are numbered in output order (scaffold order, then j
+ * ascending, L228); frisk_scan_plan returns their number.  frisk_scan scores candidates
+ * [c0,c1) (c1 = -1: to the end) and writes one entry per candidate, index (c - c0); entries
+ * whose status lacks FRISK_ROW_KEPT are windows the reference drops (no row).  cap = length of
+ * the output arrays (FRISK_E_CAP if < c1-c0).  Nullable: pi/si/cri (required with
+ * FRISK_SCAN_RIP), dbg_counts (cap x frisk_profile_len() uint32: the window's k-mer counts),
+ * dbg_meta (cap x 3: totalLen, exMax, nnTotal of L356-359). */
+int frisk_scan_plan(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int64_t* n_candidates);
+int frisk_scan(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1,
+               int64_t cap, int32_t* seq_index, int64_t* start, int64_t* stop, uint32_t* status,
+               double* kld, double* gc, double* pi, double* si, double* cri,
+               uint32_t* dbg_counts, int64_t* dbg_meta);
+
+/* Timing of the most recent launches on the context's stream, measured with HIP events:
+ * which = 0 scan kernel, 1 profile_add kernel, 2 pack kernel.  Returns milliseconds, <0 if none. */
+double frisk_last_kernel_ms(const frisk_ctx* ctx, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRISK_HIP_H */

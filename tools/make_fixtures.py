@@ -161,6 +161,12 @@ def main():
     s = put(s, 11300, "AT" * 100)
     write("k8.fa", [("k8chr", s)], width=100)
 
+    # 8. scaffolds shorter than w but longer than the small-scaffold limit (w=100, i=90 -> 85):
+    #    the jumpback slice seq[size-w:size] then has a NEGATIVE start (Python slice from the end)
+    rng = SplitMix64(707)
+    write("overshoot.fa", [("ov95", uniform(rng, 95)), ("ov86", uniform(rng, 86)), ("ov99", uniform(rng, 99)),
+                           ("ov200", uniform(rng, 200)), ("ov85", uniform(rng, 85))])
+
     return 0
 
 

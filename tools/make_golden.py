@@ -128,6 +128,7 @@ CASES = [
     ("k8", "k8.fa", None, dict(m=1, k=8, w=5000, i=1000, RIP=True), False),
     ("k8_w2000", "k8.fa", None, dict(m=1, k=8, w=2000, i=500), False),
     ("k8_m2", "k8.fa", None, dict(m=2, k=8, w=5000, i=2500, RIP=True), False),
+    ("overshoot", "overshoot.fa", None, dict(m=1, k=3, w=100, i=90, RIP=True), False),
 ]
 
 
