@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py - whole-job throughput of the frisk hot path on N MI355X (one process per GPU).
+
+A step = one pass of the hot path over the rank's resident synthetic shard:
+    phase A  profile_reset -> profile_add -> [ONE all-reduce of the raw profile over RCCL] -> finalize
+    phase B  window scan of every candidate window (kernel + D2H of the result rows)
+with the packed scaffolds already resident in HBM when the timed region starts.
+
+Workload (config.workload): BASELINE.json's metric geometry k=1..8, w=5000, i=1000 on the C5 shape
+(GRCh38-like: 24 chromosome-scale + 400 small synthetic scaffolds, ~3.1 Gb, ~7 % N) split into 8
+shards by longest-processing-time bin packing; every rank owns ONE shard (~388 Mb, ~388 k candidate
+windows), so N = 8 is the full C5 job and N < 8 is the same per-GPU work (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     - HBM roofline of the dominant kernel (scan): algorithmic bytes / HIP-event kernel time
+  cpu_baseline - the reference-shaped Python oracle timed on one host core on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+KMIN, KMAX, W, INC = 1, 8, 5000, 1000
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(engine, names_seq0_len, n_windows):
+    """Time oracle/frisk_oracle.py (the reference-shaped Python restatement, 1 core) on the first
+    `n_windows` candidate windows of scaffold 0, against the profile the GPU just built.
+    Returns (dict for the JSON line, max |KLD_gpu - KLD_oracle| on the sample)."""
+    import numpy as np
+    from oracle import frisk_oracle as O
+    from frisk_amd.hotpath import profileToMaps
+
+    sym, tl, ex, nn = engine.profile_get()
+    gmaps = profileToMaps(sym, tl, ex, nn, KMIN, KMAX)[:KMAX - KMIN + 1]
+    gmeta = {"totalLen": tl, "exMax": ex, "nnTotal": nn}
+    n_windows = min(n_windows, max(0, (names_seq0_len - W) // INC + 1))
+    span = W + (n_windows - 1) * INC
+    seq = engine.read_seq(0, 0, span).decode("ascii")
+    res = engine.scan(W, INC, c0=0, c1=n_windows)
+    t0 = time.perf_counter()
+    rows = []
+    for j in range(n_windows):                      # the regular candidates j = 0..n_windows-1 of scaffold 0
+        win = seq[j * INC:j * INC + W]
+        if O.count_acgt(win)[1] >= 0.3 * len(win):  # the reference's N filter (L237-241)
+            continue
+        rows.append(O.score_window(win, gmaps, gmeta, KMIN, KMAX))
+    dt = time.perf_counter() - t0
+    kept = np.nonzero(res.kept)[0][:len(rows)]
+    worst = max((abs(float(res.kld[r]) - row["KLD"]) for r, row in zip(kept.tolist(), rows)), default=0.0)
+    return ({"value": len(rows) / dt if dt > 0 else 0.0, "unit": "windows/s", "cores": 1, "kind": "port",
+             "sample": "oracle/frisk_oracle.py (reference-shaped Python, single thread) on the first %d kept "
+                       "windows of scaffold 0 of the same synthetic shard, k=%d..%d w=%d i=%d; %.1f s"
+                       % (len(rows), KMIN, KMAX, W, INC, dt)}, worst)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shard-scale", type=float, default=1.0,
+                    help="scale every scaffold length of the shard (testing only; 1.0 = the named workload)")
+    ap.add_argument("--cpu-windows", type=int, default=48, help="windows in the CPU-baseline sample (0 = skip)")
+    opts = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != opts.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (opts.gpus, world, opts.gpus))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from frisk_amd import Engine, synth
+    lens = [max(1, int(x * opts.shard_scale)) for x in synth.c5_shard_lens(8, rank % 8)]
+    eng = Engine(KMIN, KMAX, device=local_rank)
+    eng.synth(lens, seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0)
+    n_cand = eng.scan_plan(W, INC)
+    total_bases = sum(lens)
+
+    def step():
+        eng.profile_reset()
+        eng.profile_add(mask_host=False)
+        t_prof = eng.kernel_ms(1)
+        eng.profile_allreduce()
+        eng.profile_finalize()
+        res = eng.scan(W, INC)
+        return res, t_prof, eng.kernel_ms(0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(opts.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    scan_ms, prof_ms, rows = [], [], 0
+    for _ in range(opts.steps):
+        res, tp, ts = step()
+        scan_ms.append(ts)
+        prof_ms.append(tp)
+        rows = int(res.kept.sum())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed, float(rows), float(total_bases), float(n_cand)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rows_all, bases_all, cand_all = float(t[1]), float(t[2]), float(t[3])
+    else:
+        rows_all, bases_all, cand_all = float(rows), float(total_bases), float(n_cand)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / opts.steps
+        scan_avg = sum(scan_ms) / len(scan_ms)
+        # algorithmic bytes of one scan launch: 2-bit bases once, 40 B per emitted row, genome table once
+        b_alg = 0.25 * total_bases + 40.0 * rows + 8.0 * sum(4 ** x for x in range(KMIN, KMAX + 1))
+        achieved = b_alg / (scan_avg * 1e-3) / 1e9
+        out = {
+            "metric": "windows/sec (k=1..8, w=5kb, s=1kb)", "value": rows_all / (elapsed / opts.steps),
+            "unit": "windows/s", "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16 counts + f64 scores", "data": "synthetic",
+            "config": {"workload": "C5 shape (GRCh38-like synthetic, 24 chromosome-scale + 400 small scaffolds, 7% N), "
+                                   "one 1/8 LPT shard per GPU (N=8 is the full 3.1 Gb job), k=1..8 w=5000 i=1000; "
+                                   "step = genome profile + all-reduce + window scan, inputs packed and resident in HBM",
+                       "bases_per_gpu": total_bases, "candidate_windows_per_gpu": n_cand, "rows_per_gpu_rank0": rows,
+                       "shard_scale": opts.shard_scale},
+            "gbases_per_s": bases_all / (elapsed / opts.steps) / 1e9,
+            "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
+            "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "scan_kernel", "algorithmic_bytes_per_launch": b_alg,
+                         "note": "the path is not HBM-limited at any plausible rate (290 B/window); the binding "
+                                 "limits are LDS atomics and FP64 divide/log issue - see DESIGN.md"},
+        }
+        if opts.cpu_windows > 0:
+            cb, worst = cpu_baseline(eng, lens[0], opts.cpu_windows)
+            out["cpu_baseline"] = cb
+            out["cpu_sample_max_abs_dKLD"] = worst
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -292,18 +292,17 @@ int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t s
     return run_pack(c);
 }
 
-int frisk_seq_read(frisk_ctx* c, int32_t s, uint8_t* out, int64_t cap) {
+int frisk_seq_read(frisk_ctx* c, int32_t s, int64_t offset, int64_t n, uint8_t* out) {
     if (!c || !out) return FRISK_E_ARG;
     if (!c->have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
     if (s < 0 || s >= c->n_seq) return fail(c, FRISK_E_ARG, "sequence index out of range");
-    const int64_t n = c->seq_len[size_t(s)];
-    if (cap < n) return fail(c, FRISK_E_CAP, "buffer too small: need " + std::to_string(n));
+    if (offset < 0 || n < 0 || offset + n > c->seq_len[size_t(s)]) return fail(c, FRISK_E_ARG, "range outside the scaffold");
     if (n == 0) return FRISK_OK;
     HIPC(c, hipSetDevice(c->device));
     DevBuf<uint8_t> tmp;
     HIPC(c, tmp.reserve(size_t(n)));
     unpack_kernel<<<grid_for(n, 256, c->num_cu * 8), 256, 0, c->stream>>>(c->d_codes.p, c->d_inv.p, c->d_low.p,
-                                                                           c->seq_off[size_t(s)], n, tmp.p);
+                                                                           c->seq_off[size_t(s)] + offset, n, tmp.p);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp.p, size_t(n), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

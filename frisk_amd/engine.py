@@ -103,10 +103,11 @@ class Engine:
         self.n_seq = len(lens)
         self.seq_lens = lens
 
-    def read_seq(self, index):
-        n = self.seq_lens[index]
+    def read_seq(self, index, offset=0, n=None):
+        if n is None:
+            n = self.seq_lens[index] - offset
         out = np.empty(max(n, 1), dtype=np.uint8)
-        self._check(self._lib.frisk_seq_read(self._ctx, index, _ptr(out), n))
+        self._check(self._lib.frisk_seq_read(self._ctx, index, int(offset), int(n), _ptr(out)))
         return out[:n].tobytes()
 
     @property

@@ -46,6 +46,7 @@ enum {
 #define FRISK_ROW_KEPT        1u      /* window passed the < 30 % non-ACGT filter (L237-241)          */
 #define FRISK_ROW_ZERO_WEIGHT 2u      /* reference raises ZeroDivisionError for this window           */
 #define FRISK_ROW_JUMPBACK    4u      /* end-of-scaffold "jumpback" window (0-based start, L230-243)  */
+#define FRISK_ROW_NO_MAXMER   8u      /* no valid max-mer: the reference's KLD is the int 0 (L465)    */
 
 const char* frisk_version(void);
 
@@ -71,8 +72,9 @@ int frisk_seq_load(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* le
 int frisk_seq_synth(frisk_ctx* ctx, const int64_t* lens, int32_t n_seq, uint64_t seed,
                     double island_frac, double n_frac, double lower_frac);
 
-/* Copy the resident batch back as ASCII (canonical letters: A/T/G/C, a/t/g/c, N) - test utility. */
-int frisk_seq_read(frisk_ctx* ctx, int32_t seq_index, uint8_t* out, int64_t cap);
+/* Copy bases [offset, offset+n) of resident scaffold seq_index back as ASCII (canonical letters:
+ * A/T/G/C, a/t/g/c, N for every non-ACGT letter) - test / bench-sampling utility. */
+int frisk_seq_read(frisk_ctx* ctx, int32_t seq_index, int64_t offset, int64_t n, uint8_t* out);
 
 /* ---- phase A: genome profile (computeKmers genomeMode=True, L1442) -------------------------
  * reset -> add (once per resident batch; forward counts only) -> [all-reduce across GPUs]
