@@ -146,9 +146,8 @@ class Engine:
             torch.cuda.synchronize(t.device)
             self._check(self._lib.frisk_profile_import_device(self._ctx, C.c_void_p(t.data_ptr())))
         else:
-            t = torch.from_numpy(self.profile_raw())
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            self.profile_set_raw(t.numpy())
+            from .distributed import allreduce_raw_host
+            self.profile_set_raw(allreduce_raw_host(self.profile_raw(), group))
 
     def profile_finalize(self):
         self._check(self._lib.frisk_profile_finalize(self._ctx))

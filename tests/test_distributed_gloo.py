@@ -1,0 +1,73 @@
+"""The N>1 path on the CPU: two gloo ranks run frisk_amd.distributed.run_sharded with an oracle-backed
+engine; the gathered rows and the all-reduced profile must equal the single-process run exactly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+for p in (REPO, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from golden_util import INPUTS  # noqa: E402
+
+
+def _job(mode):
+    from oracle import frisk_oracle as O
+    if mode == "scaffold":
+        recs = list(O.iter_fasta(os.path.join(INPUTS, "smalls.fa"))) + list(O.iter_fasta(os.path.join(INPUTS, "host.fa")))
+        return recs, dict(kmin=1, kmax=4, w=400, inc=150, scaffolds_all=True, rip=True)
+    recs = list(O.iter_fasta(os.path.join(INPUTS, "markov_islands.fa")))[:1]
+    return recs, dict(kmin=1, kmax=5, w=400, inc=100, scaffolds_all=False, rip=False)
+
+
+def _run(rank, world, port, mode, out_path):
+    import torch.distributed as dist
+    from fake_engine import FakeEngine
+    from frisk_amd.distributed import run_sharded
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    recs, kw = _job(mode)
+    eng = FakeEngine(kw["kmin"], kw["kmax"])
+    rows = run_sharded(eng, [n for n, _ in recs], [s for _, s in recs], kw["w"], kw["inc"], rip=kw["rip"],
+                       scaffolds_all=kw["scaffolds_all"], mode=mode)
+    sym, tl, ex, nn = eng.profile_get()
+    if rank == 0:
+        np.save(out_path, np.array([rows, sym, (tl, ex, nn)], dtype=object), allow_pickle=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["scaffold", "range"])
+def test_two_ranks_equal_one(tmp_path, mode):
+    single = str(tmp_path / "single.npy")
+    double = str(tmp_path / "double.npy")
+    _run(0, 1, 0, mode, single)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_run, args=(2, port, mode, double), nprocs=2, join=True)
+    a = np.load(single, allow_pickle=True)
+    b = np.load(double, allow_pickle=True)
+    assert len(a[0]) > 5
+    assert np.array_equal(a[1], b[1]) and tuple(a[2]) == tuple(b[2])      # profile: identical after the all-reduce
+    assert len(a[0]) == len(b[0])
+    for ra, rb in zip(a[0], b[0]):
+        assert ra[:4] == rb[:4]
+        for x, y in zip(ra[4:], rb[4:]):
+            assert (x != x and y != y) or x == y
+
+
+def test_lpt_and_ranges():
+    from frisk_amd.distributed import choose_mode, lpt_shards, split_range
+    lens = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643]
+    bins = lpt_shards(lens, 2)
+    assert sorted(bins[0] + bins[1]) == list(range(len(lens)))
+    loads = [sum(lens[s] for s in b) for b in bins]
+    assert max(loads) <= 1.1 * min(loads)
+    assert choose_mode(lens, 2) == "scaffold" and choose_mode([248956422], 8) == "range"
+    parts = [split_range(1001, r, 8) for r in range(8)]
+    assert parts[0][0] == 0 and parts[-1][1] == 1001 and all(parts[i][1] == parts[i + 1][0] for i in range(7))
