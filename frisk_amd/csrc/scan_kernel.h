@@ -81,7 +81,7 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
     L.orphans = o;
     o += uint32_t((k8 ? orphan_cap : 0) * 2 + 15) / 16 * 16;
     L.misc = o;
-    o += 16 * 4 + 2 * 16 * 8 + 16;   // 16 u32 counters, 2 x 16 doubles of reduction scratch
+    o += 16 * 4 + 16 * 4 * 8 + 16;   // 16 u32 counters, 16 waves x 2 x 128-bit reduction scratch
     L.total = (o + 15) / 16 * 16;
     return L;
 }
@@ -114,22 +114,61 @@ struct WinTables {
     }
 };
 
+// ---- order-independent summation ---------------------------------------------------------------------
+// Which lane becomes the representative of a max-mer depends on the arrival order of LDS atomics, so a
+// floating-point sum over representatives would depend on timing.  Every per-window sum (the two IVOM
+// normalisers and the divergence) is therefore accumulated in 128-bit fixed point (hi: units of 2^-40,
+// lo: units of 2^-104).  An un-normalised IVOM value is < 1 and a window has < 2^16 max-mers, so sums stay
+// below 2^16 << 2^23; every double >= 2^-51 converts exactly, smaller ones are truncated at 2^-104.
+// Integer addition is associative, so results are bit-identical across runs, builds, grids and GPUs.
+struct Fix128 {
+    long long hi;               // units of 2^-40
+    unsigned long long lo;      // units of 2^-104
+};
+
+__device__ inline Fix128 fix_from_double(double x) {
+    const double s = x * 0x1p40;            // exact scaling
+    double f = floor(s);
+    double r = s - f;                       // in [0, 1]; exactly 1.0 only for a tiny negative s
+    if (r >= 1.0) { f += 1.0; r = 0.0; }
+    Fix128 q;
+    q.hi = (long long)f;
+    q.lo = (unsigned long long)(r * 0x1p64);
+    return q;
+}
+
+__device__ inline void fix_add(Fix128& a, const Fix128& b) {
+    const unsigned long long lo = a.lo + b.lo;
+    a.hi += b.hi + (lo < a.lo ? 1 : 0);
+    a.lo = lo;
+}
+
+__device__ inline double fix_to_double(const Fix128& a) {
+    return double(a.hi) * 0x1p-40 + double(a.lo) * 0x1p-104;
+}
+
+// sum two accumulators over the workgroup; every thread returns the same totals
 template <int NW>
-__device__ inline void block_sum2(double& a, double& b, double* scratch, int tid) {
+__device__ inline void block_sum2(Fix128& a, Fix128& b, unsigned long long* scratch, int tid) {
     for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_down(a, o);
-        b += __shfl_down(b, o);
+        Fix128 ta, tb;
+        ta.hi = __shfl_down(a.hi, o); ta.lo = __shfl_down(a.lo, o);
+        tb.hi = __shfl_down(b.hi, o); tb.lo = __shfl_down(b.lo, o);
+        fix_add(a, ta);
+        fix_add(b, tb);
     }
     __syncthreads();                       // scratch free (previous readers done)
     if ((tid & 63) == 0) {
-        scratch[tid >> 6] = a;
-        scratch[NW + (tid >> 6)] = b;
+        unsigned long long* p = scratch + (tid >> 6) * 4;
+        p[0] = (unsigned long long)a.hi; p[1] = a.lo; p[2] = (unsigned long long)b.hi; p[3] = b.lo;
     }
     __syncthreads();
-    double sa = 0.0, sb = 0.0;
-    for (int w = 0; w < NW; ++w) {         // fixed order: deterministic, identical in every thread
-        sa += scratch[w];
-        sb += scratch[NW + w];
+    Fix128 sa = {0, 0}, sb = {0, 0};
+    for (int w = 0; w < NW; ++w) {
+        const unsigned long long* p = scratch + w * 4;
+        Fix128 ta = {(long long)p[0], p[1]}, tb = {(long long)p[2], p[3]};
+        fix_add(sa, ta);
+        fix_add(sb, tb);
     }
     a = sa;
     b = sb;
@@ -150,7 +189,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
     uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
     uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L.orphans);
     uint32_t* misc = reinterpret_cast<uint32_t*>(lds + L.misc);
-    double* scratch = reinterpret_cast<double*>(lds + L.misc + M_COUNT * 4);
+    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds + L.misc + M_COUNT * 4);
     const int ks = K8 ? 6 : kmax;                       // highest order kept in the small tables
 
     // one-time clear of the histograms
@@ -322,7 +361,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
 
             // ---- phase 2: IVOM of every present max-mer, window side (L394-450) and genome side (table) --
             double iw_keep[ITS > 0 ? ITS : 1], ig_keep[ITS > 0 ? ITS : 1];
-            double Sw = 0.0, Sg = 0.0;
+            Fix128 accw = {0, 0}, accg = {0, 0};
             bool zero_w = false;
             auto window_ivom = [&](uint32_t code) -> double {
                 unsigned long long W = 0;
@@ -350,7 +389,8 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                         const double Ig = P.ig[code];
                         zero_w |= (Ig != Ig);
                         iw_keep[it] = Iw; ig_keep[it] = Ig;
-                        Sw += Iw; Sg += Ig;
+                        fix_add(accw, fix_from_double(Iw));
+                        if (Ig == Ig) fix_add(accg, fix_from_double(Ig));
                     }
                 }
             } else {
@@ -360,17 +400,20 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                         const double Iw = window_ivom(code);
                         const double Ig = P.ig[code];
                         zero_w |= (Ig != Ig);
-                        Sw += Iw; Sg += Ig;
+                        fix_add(accw, fix_from_double(Iw));
+                        if (Ig == Ig) fix_add(accg, fix_from_double(Ig));
                     }
                 }
             }
             if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
-            block_sum2<NW>(Sw, Sg, scratch, tid);           // sumWindowIVOM of both sides (L450)
+            block_sum2<NW>(accw, accg, scratch, tid);       // sumWindowIVOM of both sides (L450)
+            const double Sw = fix_to_double(accw), Sg = fix_to_double(accg);
 
             // ---- phase 3: normalise (L453-454) and accumulate the divergence (L465-470) ----------------
-            double acc = 0.0, unused = 0.0;
+            Fix128 acck = {0, 0}, unused = {0, 0};
             const double LN2 = 0.69314718055994530942;      // math.log(x, 2) == log(x) / log(2.0)
             auto term = [&](double Iw, double Ig) -> double {
+                if (!(Ig == Ig) || !(Iw == Iw)) return 0.0;          // zero-weight window: flagged, value unused
                 const double pw = Iw / Sw;
                 const double pg = Ig / Sg;
                 return (pg != 0.0) ? pw * (log(pw / pg) / LN2) : 0.0;
@@ -378,15 +421,16 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             if (ITS > 0) {
 #pragma unroll
                 for (int it = 0; it < ITS; ++it)
-                    if ((repmask >> it) & 1ull) acc += term(iw_keep[it], ig_keep[it]);
+                    if ((repmask >> it) & 1ull) fix_add(acck, fix_from_double(term(iw_keep[it], ig_keep[it])));
             } else {
                 for (int it = 0; it * NT < n; ++it)
                     if ((repmask >> it) & 1ull) {
                         const uint32_t code = code_at(it);
-                        acc += term(window_ivom(code), P.ig[code]);
+                        fix_add(acck, fix_from_double(term(window_ivom(code), P.ig[code])));
                     }
             }
-            block_sum2<NW>(acc, unused, scratch, tid);
+            block_sum2<NW>(acck, unused, scratch, tid);
+            const double acc = fix_to_double(acck);
             const uint32_t flags_lds = misc[M_FLAGS];
 
             // RIP indices from the window's dinucleotide counts (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3

@@ -1,0 +1,231 @@
+"""GPU parity beyond the golden fixtures: the HIP path (through the C ABI) against the numpy oracle on
+seeded synthetic scaffolds at sizes the oracle finishes in seconds, plus size-independent properties at
+BASELINE.json's full single-GPU sizes.  Integer work bit-exact; KLD within KLD_TOL (north star: 1e-6)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KLD_TOL = 1e-10
+
+
+def make_engine(kmin, kmax):
+    from frisk_amd import Engine
+    return Engine(kmin, kmax)
+
+
+def oracle_rows(seqs, kmin, kmax, w, inc, mask_host=False, scaffolds_all=False, rip=False):
+    from oracle import frisk_oracle_np as N
+    prof = N.genome_profile(seqs, kmin, kmax, mask_host=mask_host)
+    rows = N.scan([(str(i), s) for i, s in enumerate(seqs)], prof, kmin, kmax, w, inc, scaffolds_all, rip)
+    return prof, rows
+
+
+def synth_seqs(lens, seed, **kw):
+    from frisk_amd import synth
+    return [synth.scaffold(n, seed, i, **kw) for i, n in enumerate(lens)]
+
+
+def test_device_generator_equals_host_generator():
+    lens = [10000, 4096, 4097, 1, 33000, 70001]
+    kw = dict(island_frac=0.4, n_frac=0.25, lower_frac=0.3)
+    with make_engine(1, 4) as e:
+        e.synth(lens, seed=99, **kw)
+        host = synth_seqs(lens, 99, **kw)
+        for i in range(len(lens)):
+            assert e.read_seq(i) == host[i], "scaffold %d differs" % i
+        assert e.read_seq(4, 100, 50) == host[4][100:150]
+
+
+def test_pack_roundtrip_all_bytes():
+    seq = bytes(range(1, 256)) * 3 + b"ACGTacgtNnRYKM-*"
+    with make_engine(1, 3) as e:
+        e.load([seq, b"", b"A"])
+        back = e.read_seq(0)
+        expect = bytes(c if c in b"ACGTacgt" else ord("N") for c in seq)
+        assert back == expect
+        assert e.read_seq(1) == b"" and e.read_seq(2) == b"A"
+
+
+@pytest.mark.parametrize("kmin,kmax,w,inc,mask_host,rip", [
+    (1, 8, 5000, 1000, False, True),      # the metric's geometry
+    (1, 6, 5000, 500, False, True),       # C2
+    (1, 8, 2000, 500, False, False),      # C4
+    (2, 7, 3000, 700, True, True),
+    (3, 5, 777, 100, False, False),
+    (8, 8, 5000, 2500, False, False),
+    (1, 1, 600, 600, False, False),
+])
+def test_scan_matches_numpy_oracle(kmin, kmax, w, inc, mask_host, rip):
+    from frisk_amd import _ffi
+    lens = [150000, 61234, 5000, 8751, 300]
+    seqs = synth_seqs(lens, 7, island_frac=0.15, n_frac=0.12, lower_frac=0.08)
+    (sym, meta), rows = oracle_rows(seqs, kmin, kmax, w, inc, mask_host=mask_host, rip=rip and kmin <= 2 <= kmax)
+    with make_engine(kmin, kmax) as e:
+        e.load(seqs)
+        e.profile_reset()
+        e.profile_add(mask_host=mask_host)
+        e.profile_finalize()
+        gsym, tl, ex, nn = e.profile_get()
+        assert np.array_equal(gsym, sym) and (tl, ex, nn) == tuple(meta)
+        res = e.scan(w, inc, rip=rip and kmin <= 2 <= kmax)
+        kept = np.nonzero(res.kept)[0]
+        assert len(kept) == len(rows) and len(rows) > 20
+        worst = 0.0
+        for r, exp in zip(kept.tolist(), rows):
+            assert (str(res.seq_index[r]), int(res.start[r]), int(res.stop[r])) == (exp["name"], exp["start"], exp["stop"])
+            if "error" in exp:
+                assert res.status[r] & _ffi.ROW_ZERO_WEIGHT
+                continue
+            assert not (res.status[r] & _ffi.ROW_ZERO_WEIGHT)
+            worst = max(worst, abs(float(res.kld[r]) - exp["KLD"]))
+            assert float(res.gc[r]) == exp["GC"]
+            if rip and kmin <= 2 <= kmax:
+                got = (float(res.pi[r]), float(res.si[r]), float(res.cri[r]))
+                assert all((a != a and b != b) or a == b for a, b in zip(got, exp["RIP"]))
+        assert worst <= KLD_TOL, worst
+        # bit-exact per-window counts on a sample of candidates (the full dump is large at K=8)
+        c0 = int(kept[len(kept) // 3])
+        dbg = e.scan(w, inc, c0=c0, c1=min(res.n_candidates, c0 + 12), debug=True)
+        cand_to_row = {int(c): i for i, c in enumerate(kept.tolist())}
+        checked = 0
+        for t in range(len(dbg)):
+            if dbg.kept[t]:
+                exp = rows[cand_to_row[c0 + t]]
+                assert np.array_equal(dbg.counts[t].astype(np.int64), exp["counts"])
+                assert dbg.meta[t].tolist() == exp["meta"]
+                assert dbg.kld[t] == res.kld[c0 + t]            # debug build of the kernel: same bits
+                checked += 1
+        assert checked > 0
+
+
+def test_profile_is_linear_over_ranges_and_batches():
+    lens = [50000, 20011, 999]
+    seqs = synth_seqs(lens, 11, island_frac=0.1, n_frac=0.1, lower_frac=0.1)
+    for kmin, kmax in ((1, 8), (2, 5)):
+        with make_engine(kmin, kmax) as e:
+            e.load(seqs)
+            e.profile_reset()
+            e.profile_add()
+            whole = e.profile_raw()
+            e.profile_reset()
+            P = e.padded_len
+            cuts = [0, 1, 4097, P // 3, P // 2 + 5, P]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                e.profile_add(pos_begin=a, pos_end=b)
+            assert np.array_equal(e.profile_raw(), whole)
+            # two batches accumulate: load scaffolds separately
+            e.profile_reset()
+            for s in seqs:
+                e.load([s])
+                e.profile_add()
+            assert np.array_equal(e.profile_raw(), whole)
+            # finalised profile: strand-symmetric, and marginals consistent with the oracle
+            e.profile_finalize()
+            sym, tl, ex, nn = e.profile_get()
+            from oracle import frisk_oracle_np as N
+            osym, ometa = N.genome_profile(seqs, kmin, kmax)
+            assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+            for x in range(kmin, kmax + 1):
+                o = N.table_offset(kmin, x)
+                t = sym[o:o + 4 ** x]
+                assert np.array_equal(t, t[N.revcomp_index(x)])
+
+
+def test_scan_ranges_concatenate_and_runs_are_deterministic():
+    lens = [120000, 33333]
+    seqs = synth_seqs(lens, 5, island_frac=0.1, n_frac=0.05)
+    with make_engine(1, 8) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        full = e.scan(5000, 1000, rip=True)
+        again = e.scan(5000, 1000, rip=True)
+        for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):
+            assert np.array_equal(getattr(full, f), getattr(again, f), equal_nan=True), f
+        n = full.n_candidates
+        cuts = [0, 1, 7, n // 2, n - 3, n]
+        parts = [e.scan(5000, 1000, rip=True, c0=a, c1=b) for a, b in zip(cuts[:-1], cuts[1:])]
+        for f in ("seq_index", "start", "stop", "status", "kld", "gc", "cri"):
+            cat = np.concatenate([getattr(p, f) for p in parts])
+            assert np.array_equal(cat, getattr(full, f), equal_nan=True), f
+        # a profile installed from a cache gives the same scores as the computed one
+        sym, tl, ex, nn = e.profile_get()
+        e.profile_reset()
+        e.profile_set(sym, tl, ex, nn)
+        cached = e.scan(5000, 1000, rip=True)
+        assert np.array_equal(cached.kld, full.kld, equal_nan=True)
+
+
+def test_error_paths_and_edge_batches():
+    from frisk_amd import _ffi
+    with make_engine(3, 5) as e:
+        with pytest.raises(_ffi.FriskHipError) as ei:
+            e.scan_plan(100, 10)
+        assert ei.value.code == _ffi.E_STATE
+        e.load([b"ACGT" * 100])
+        with pytest.raises(_ffi.FriskHipError) as ei:
+            e.scan(100, 10)
+        assert ei.value.code == _ffi.E_STATE               # profile not finalised
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        with pytest.raises(_ffi.FriskHipError) as ei:
+            e.scan(100, 10, rip=True)                        # kmin > 2: no dinucleotide table (reference L478)
+        assert ei.value.code == _ffi.E_ARG
+        with pytest.raises(_ffi.FriskHipError) as ei:
+            e.scan(70000, 10)
+        assert ei.value.code == _ffi.E_ARG
+        with pytest.raises(_ffi.FriskHipError):
+            e.profile_add(pos_begin=5, pos_end=10 ** 9)
+    with pytest.raises(_ffi.FriskHipError):
+        make_engine(1, 9)
+    with pytest.raises(_ffi.FriskHipError):
+        make_engine(0, 3)
+    with make_engine(1, 8) as e:
+        e.load([])                                            # empty batch
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        assert sym.sum() == 0 and (tl, ex, nn) == (0, 0, 0)
+        assert len(e.scan(5000, 1000)) == 0
+        e.load([b"", b"N" * 9000, b"acgt" * 3000, b"ACGTTGCA" * 2000])
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        res = e.scan(5000, 1000)
+        # all-N and all-lowercase scaffolds: every window is dropped (lowercase counts as N for the filter)
+        assert res.kept.sum() == 16 and set(res.seq_index[res.kept].tolist()) == {3}
+        assert np.all(res.kld[res.kept] > -1e-12)
+
+
+@pytest.mark.parametrize("shape", ["C2", "C3"])
+def test_full_size_properties(shape):
+    """BASELINE configs at full size: properties that need no oracle run."""
+    from frisk_amd import synth
+    if shape == "C2":
+        lens, kmin, kmax, w, inc, nfrac = synth.C2_LENS, 1, 6, 5000, 500, 0.0
+    else:
+        lens, kmin, kmax, w, inc, nfrac = synth.C3_LENS, 1, 8, 5000, 1000, 0.001
+    with make_engine(kmin, kmax) as e:
+        e.synth(lens, seed=2 if shape == "C2" else 3, island_frac=0.02, n_frac=nfrac)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        assert tl == sum(lens)
+        top = sym[-(4 ** kmax):]
+        assert top.sum() == 2 * (sum(max(0, n - kmax + 1) for n in lens) - ex)      # every counted word twice (L350-351)
+        res = e.scan(w, inc)
+        assert res.n_candidates == sum(n // inc for n in lens)                      # floor(size/i) per scaffold (L228)
+        k = res.kept
+        assert np.all(np.isfinite(res.kld[k])) and np.all(res.kld[k] > -1e-12)      # a KL divergence is >= 0
+        assert np.all((res.gc[k] >= 0) & (res.gc[k] <= 1))
+        assert not np.any(res.zero_weight)
+        # rows come out in scaffold order, starts ascending; jumpback rows of a scaffold are identical duplicates
+        assert np.all(np.diff(res.seq_index) >= 0)
+        from frisk_amd import _ffi
+        jb = (res.status & _ffi.ROW_JUMPBACK) != 0
+        for s in range(len(lens)):
+            m = (res.seq_index == s)
+            j = np.nonzero(m & jb)[0]
+            assert len(j) == len([x for x in range(0, lens[s] - inc + 1, inc) if x + w > lens[s]])
+            if len(j):
+                assert np.all(res.start[j] == lens[s] - w) and np.all(res.stop[j] == lens[s])
+                assert len(set(res.kld[j].tolist())) == 1
+            reg = np.nonzero(m & ~jb)[0]
+            assert np.array_equal(res.start[reg], 1 + inc * np.arange(len(reg)))
+        # islands exist: the score distribution has a tail
+        assert res.kld[k].max() > 1.3 * np.median(res.kld[k])
