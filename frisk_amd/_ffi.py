@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfrisk_hip.so")
+LIB_PATH = os.environ.get("FRISK_HIP_LIB") or os.path.join(_HERE, "libfrisk_hip.so")   # override: kernel experiments
 
 OK, E_ARG, E_HIP, E_STATE, E_CAP, E_ZERO_WEIGHT = 0, -1, -2, -3, -4, -5
 SCAN_RIP, SCAN_SCAFFOLDS_ALL = 1, 2

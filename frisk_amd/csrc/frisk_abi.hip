@@ -328,17 +328,21 @@ int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
     if (p0 < 0 || p1 > c->padded_len || p0 > p1) return fail(c, FRISK_E_ARG, "position range outside the batch");
     HIPC(c, hipSetDevice(c->device));
     c->profile_final = false;
-    const bool lds_hist = c->nprof <= 8192;
-    const int grid = grid_for(p1 - p0, 256 * 16, c->num_cu * 8);
+    // order-K table privatised in LDS (u32): split in two halves at K = 8 (256 KiB does not fit a CU)
+    const int halves = (c->kmax == 8) ? 2 : 1;
+    const size_t lds = (size_t(1) << (2 * c->kmax)) / size_t(halves) * 4;
+    const int64_t span = p1 - p0;
+    int64_t nchunks = std::min<int64_t>(std::max<int64_t>(1, span / 65536), int64_t(c->num_cu) * (halves == 2 ? 1 : 2));
+    const int64_t chunk_len = (span + nchunks - 1) / std::max<int64_t>(nchunks, 1);
+    nchunks = chunk_len > 0 ? (span + chunk_len - 1) / chunk_len : 0;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
-    if (p1 > p0) {
+    if (span > 0) {
         auto raw = reinterpret_cast<unsigned long long*>(c->d_raw.p);
-        if (lds_hist)
-            profile_add_kernel<true><<<grid, 256, size_t(c->nprof) * 4, c->stream>>>(
-                c->d_codes.p, c->d_inv.p, c->d_low.p, p0, p1, c->kmin, c->kmax, mask_host ? 1 : 0, int(c->nprof), raw);
-        else
-            profile_add_kernel<false><<<grid, 256, 0, c->stream>>>(c->d_codes.p, c->d_inv.p, c->d_low.p, p0, p1, c->kmin,
-                                                                  c->kmax, mask_host ? 1 : 0, int(c->nprof), raw);
+        HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(profile_add_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max<size_t>(lds, 16))));
+        profile_add_kernel<<<int(nchunks) * halves, FRISK_PROF_NT, std::max<size_t>(lds, 16), c->stream>>>(
+            c->d_codes.p, c->d_inv.p, c->d_low.p, p0, p1, c->kmin, c->kmax, mask_host ? 1 : 0, int(c->nprof), halves,
+            chunk_len, raw);
     }
     HIPC(c, hipGetLastError());
     HIPC(c, hipEventRecord(c->ev1, c->stream));

@@ -70,55 +70,69 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict_
 // which is exact, including scaffold ends and N-adjacent positions.  `raw` = the D tables (profile
 // layout) followed by {totalLen, #K-mer start positions, nnTotal, 0}; everything in it is a plain sum
 // over positions, hence summable across batches and across GPUs.
-// LDS_HIST: when the whole profile fits, privatise it in LDS (u32) and flush once per block.
+// The order-K table (all but a vanishing share of the updates) is privatised per workgroup in LDS as 32-bit
+// counters and flushed once with one global atomic per non-empty bin.  4^8 x 4 B = 256 KiB does not fit a
+// CU's 160 KiB, so at K = 8 the k-mer space is split in two halves by the leading bit of the code and a
+// workgroup makes its pass over its chunk for ONE half (grid = chunks x halves; the sequence is 0.5 B/base,
+// reading it twice is free).  Orders below K (positions next to an invalid base or a scaffold end) go straight
+// to global atomics, as do the three scalars (one atomic per wave).  Half 0 alone counts those.
 // ------------------------------------------------------------------------------------------------
-template <bool LDS_HIST>
-__global__ __launch_bounds__(256) void profile_add_kernel(const uint32_t* __restrict__ codes,
-                                                           const uint32_t* __restrict__ inv,
-                                                           const uint32_t* __restrict__ low, int64_t p0, int64_t p1,
-                                                           int kmin, int kmax, int mask_host, int nprof,
-                                                           unsigned long long* __restrict__ raw) {
+#define FRISK_PROF_NT 1024
+
+__global__ __launch_bounds__(FRISK_PROF_NT) void profile_add_kernel(const uint32_t* __restrict__ codes,
+                                                                     const uint32_t* __restrict__ inv,
+                                                                     const uint32_t* __restrict__ low, int64_t p0, int64_t p1,
+                                                                     int kmin, int kmax, int mask_host, int nprof,
+                                                                     int halves, int64_t chunk_len,
+                                                                     unsigned long long* __restrict__ raw) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    if (LDS_HIST) {
-        for (int b = threadIdx.x; b < nprof; b += blockDim.x) hist[b] = 0;
-        __syncthreads();
-    }
+    const int half = int(blockIdx.x) % halves;
+    const int64_t chunk = int64_t(blockIdx.x) / halves;
+    const uint32_t nbins = (1u << (2 * kmax)) / uint32_t(halves);
+    for (uint32_t b = threadIdx.x; b < nbins / 4; b += blockDim.x) reinterpret_cast<uint4*>(hist)[b] = make_uint4(0, 0, 0, 0);
+    if (nbins < 4) for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
     unsigned long long tot = 0, kpos = 0, nn = 0;
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t p = p0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < p1; p += stride) {
+    const int64_t cb = p0 + chunk * chunk_len;
+    int64_t ce = cb + chunk_len;
+    if (ce > p1) ce = p1;
+    const int64_t offK = table_offset(kmin, kmax);
+    for (int64_t p = cb + threadIdx.x; p < ce; p += blockDim.x) {
         const uint32_t inv8 = fetch_mask8(inv, p), low8 = fetch_mask8(low, p);
-        const uint32_t pad8 = inv8 & low8;
-        const uint32_t real = ((pad8 >> 7) & 1u) ^ 1u;
         const uint32_t eff = inv8 | (mask_host ? low8 : 0u);
         int run = lead_clear8(eff);
         run = run < kmax ? run : kmax;
-        if (run >= kmin) {
+        if (run == kmax) {
+            const uint32_t code = fetch_codes16(codes, p) >> (16 - 2 * kmax);
+            if (int(code / nbins) == half) atomicAdd(&hist[code & (nbins - 1)], 1u);
+        } else if (half == 0 && run >= kmin) {
             const uint32_t code = fetch_codes16(codes, p) >> (16 - 2 * run);
-            const int64_t bin = table_offset(kmin, run) + code;
-            if (LDS_HIST) atomicAdd(&hist[bin], 1u);
-            else atomicAdd(&raw[bin], 1ull);
+            atomicAdd(&raw[table_offset(kmin, run) + code], 1ull);
         }
-        tot += real;
-        nn += real & (((inv8 | low8) >> 7) & 1u);            // not an uppercase A/T/G/C (countN, L106-118)
-        kpos += ((pad8 >> (8 - kmax)) == 0u) ? 1u : 0u;       // a K-mer can start here (L329)
-    }
-    // wave-level reduction of the three scalars, one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) {
-        tot += __shfl_down(tot, o);
-        kpos += __shfl_down(kpos, o);
-        nn += __shfl_down(nn, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (tot) atomicAdd(&raw[nprof + 0], tot);
-        if (kpos) atomicAdd(&raw[nprof + 1], kpos);
-        if (nn) atomicAdd(&raw[nprof + 2], nn);
-    }
-    if (LDS_HIST) {
-        __syncthreads();
-        for (int b = threadIdx.x; b < nprof; b += blockDim.x) {
-            const uint32_t v = hist[b];
-            if (v) atomicAdd(&raw[b], (unsigned long long)v);
+        if (half == 0) {
+            const uint32_t pad8 = inv8 & low8;
+            const uint32_t real = ((pad8 >> 7) & 1u) ^ 1u;
+            tot += real;
+            nn += real & (((inv8 | low8) >> 7) & 1u);            // not an uppercase A/T/G/C (countN, L106-118)
+            kpos += ((pad8 >> (8 - kmax)) == 0u) ? 1u : 0u;       // a K-mer can start here (L329)
         }
+    }
+    if (half == 0) {                     // wave-level reduction of the three scalars, one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) {
+            tot += __shfl_down(tot, o);
+            kpos += __shfl_down(kpos, o);
+            nn += __shfl_down(nn, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (tot) atomicAdd(&raw[nprof + 0], tot);
+            if (kpos) atomicAdd(&raw[nprof + 1], kpos);
+            if (nn) atomicAdd(&raw[nprof + 2], nn);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) {
+        const uint32_t v = hist[b];
+        if (v) atomicAdd(&raw[offK + uint32_t(half) * nbins + b], (unsigned long long)v);
     }
 }
 

@@ -5,15 +5,21 @@
 //   side) (L369-457) -> KLD (L459-472) -> calcGC (L120-137) [-> calcRIP (L474-495)].
 //
 // Mapping onto CDNA4: one 1024-thread workgroup (16 wavefronts) owns one window at a time and keeps the
-// window's k-mer histograms in LDS:
-//   * orders kmin..min(K,7) : dense 16-bit counters (two per LDS dword, updated with 32-bit ds_add)
-//   * order 8 (K = 8)        : dense 16-bit counters, 128 KiB - the reason a workgroup owns a whole CU;
-//                              order 7 is then NOT stored: c7(q) = sum of the four order-8 children of q
-//                              (one 8-byte LDS read) + the few "orphan" 7-mers whose 8th base is missing
-//                              (window tail, or an invalid base), kept in a short LDS list.
-// Each position does one returning LDS atomic on its max-mer; the lane that sees the old value 0 becomes
-// the *representative* of that max-mer and later evaluates its IVOM recursion, so no scan over the 4^K
-// bins is ever needed, and bins are re-zeroed by their representatives instead of a 128 KiB clear.
+// window's k-mer histograms in LDS as dense 16-bit counters (two per dword, updated with 32-bit ds_add):
+//   * every position does ONE update of the "small" tables (orders kmin..6, or kmin..K when K <= 7): to the
+//     table of order r = min(run, top) at the code of its longest valid word; lower orders then follow by an
+//     in-LDS marginalisation  C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b]  (exact, incl. window tail and N-adjacent
+//     positions) - this replaces K updates per position, most of them on the few, heavily contended
+//     low-order bins;
+//   * order 8 (K = 8): dense 16-bit counters, 128 KiB - the reason a workgroup owns a whole CU; order 7 is
+//     then NOT stored: c7(q) = sum of the four order-8 children of q (one 8-byte LDS read) + the few "orphan"
+//     7-mers whose 8th base is missing (window tail, or an invalid base), kept in a short LDS list.
+// The update of the max-mer table is a returning atomic; the lane that sees the old value 0 becomes the
+// *representative* of that max-mer and later evaluates its IVOM recursion, so no scan over the 4^K bins is
+// ever needed, and bins are re-zeroed by their representatives instead of a 128 KiB clear.
+// The IVOM value after order x depends only on the x-mer prefix, so the first five recursion steps are
+// evaluated once per present 5-mer (<= 1024 per window) into an LDS table and every representative continues
+// from there: 3 instead of 8 division-heavy steps per max-mer at K = 8, with bit-identical results.
 // FP64 throughout (the KLD sum cancels from O(1) terms to O(1e-2)); contraction off so that every
 // product/sum rounds exactly as CPython's does.  No MFMA: this is histogramming + a scalar recurrence.
 #pragma once
@@ -63,14 +69,20 @@ struct LdsLayout {
     uint32_t small;     // byte offset of the small tables (orders kmin..ks), u16 bins
     uint32_t small_bytes;
     uint32_t orphans;   // u16 list
+    uint32_t pre_i;     // f64[4^lv]: IVOM value after order lv, per lv-mer prefix
+    uint32_t pre_w;     // u32[4^lv]: running weight sum after order lv
     uint32_t misc;      // counters + reduction scratch
     uint32_t total;
 };
+
+// order at which the recursion is shared between max-mers (0 = not shared)
+__host__ __device__ inline int shared_level(int kmin, int kmax) { return (kmin <= 5 && kmax >= 6) ? 5 : 0; }
 
 __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap) {
     LdsLayout L;
     const bool k8 = (kmax == 8);
     const int ks = k8 ? 6 : kmax;
+    const int lv = shared_level(kmin, kmax);
     uint32_t o = 0;
     L.t8 = o;
     if (k8) o += FRISK_T8_BYTES;
@@ -80,6 +92,10 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
     o += L.small_bytes;
     L.orphans = o;
     o += uint32_t((k8 ? orphan_cap : 0) * 2 + 15) / 16 * 16;
+    L.pre_i = o;
+    if (lv) o += (1u << (2 * lv)) * 8;
+    L.pre_w = o;
+    if (lv) o += (1u << (2 * lv)) * 4;
     L.misc = o;
     o += 16 * 4 + 16 * 4 * 8 + 16;   // 16 u32 counters, 16 waves x 2 x 128-bit reduction scratch
     L.total = (o + 15) / 16 * 16;
@@ -127,6 +143,9 @@ struct Fix128 {
 };
 
 __device__ inline Fix128 fix_from_double(double x) {
+#if defined(FRISK_ABLATE) && (FRISK_ABLATE & 8)
+    Fix128 z; z.hi = (long long)__double_as_longlong(x); z.lo = 0; return z;
+#endif
     const double s = x * 0x1p40;            // exact scaling
     double f = floor(s);
     double r = s - f;                       // in [0, 1]; exactly 1.0 only for a tiny negative s
@@ -187,10 +206,14 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
     const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap);
     uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L.t8);
     uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
+    uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L.small);
     uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L.orphans);
+    double* pre_i = reinterpret_cast<double*>(lds + L.pre_i);
+    uint32_t* pre_w = reinterpret_cast<uint32_t*>(lds + L.pre_w);
     uint32_t* misc = reinterpret_cast<uint32_t*>(lds + L.misc);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds + L.misc + M_COUNT * 4);
     const int ks = K8 ? 6 : kmax;                       // highest order kept in the small tables
+    const int lv = shared_level(kmin, kmax);            // recursion shared up to this order (0: not shared)
 
     // one-time clear of the histograms
     if (K8) for (int i = tid; i < FRISK_T8_BYTES / 16; i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
         for (int64_t cand = cb; cand < ce; ++cand) {
             // ---- which scaffold / window is this candidate? (uniform across the workgroup)
             if (cand < d.cand0 || cand >= d.cand0 + d.ncand) {
-                int lo = 0, hi = P.n_desc - 1;          // last descriptor with cand0 <= cand and ncand > 0
+                int lo = 0, hi = P.n_desc - 1;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     if (P.descs[mid].cand0 <= cand) lo = mid; else hi = mid - 1;
@@ -249,27 +272,64 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             const int64_t g0 = d.off + st;
             const int64_t row = cand - P.c0;
 
-            // ---- phase 0: uppercase base composition (calcGC L120-137, countN L106-118) -------------
+            // ---- phase 1: one pass over the window's positions ------------------------------------------
+            //   * uppercase base composition (calcGC L120-137, countN L106-118) by wave ballots
+            //   * ONE small-table update per position + the max-mer update that elects representatives
+            // (done before the N filter is known: 93 % of windows pass it, the others are cleaned up below)
+            unsigned long long repmask = 0;
             {
-                uint32_t cA = 0, cT = 0, cG = 0, cC = 0;
-                for (int jj = tid; jj - lane < n; jj += NT) {
-                    bool up = false;
+                uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
+                int it = 0;
+                for (int jj = tid; jj - lane < n; jj += NT, ++it) {
+                    bool is_top = false, up = false;
                     uint32_t c2 = 0;
                     if (jj < n) {
                         const int64_t g = g0 + jj;
-                        up = !(fetch_mask1(P.inv, g) | fetch_mask1(P.low, g));
-                        c2 = fetch_code2(P.codes, g);
+                        const uint32_t c16 = fetch_codes16(P.codes, g);
+                        const uint32_t inv8 = fetch_mask8(P.inv, g);
+                        up = !((inv8 >> 7) | fetch_mask1(P.low, g));
+                        c2 = c16 >> 14;
+                        int run = lead_clear8(inv8);                         // window words are upper-cased: L334-335
+                        const int rem = n - jj;
+                        run = run < rem ? run : rem;
+                        run = run < kmax ? run : kmax;
+                        if (K8) {
+                            const int rs = run < 6 ? run : 6;
+                            if (rs >= kmin) {
+                                const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (16 - 2 * rs));
+                                atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                            }
+                            if (run == 8) {
+                                const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
+                                is_top = true;
+                                if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                            } else if (run == 7 && kmin <= 7) {
+                                const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
+                                orph[slot] = uint16_t(c16 >> 2);
+                            }
+                        } else if (run >= kmin) {
+                            const uint32_t b = uint32_t(table_offset(kmin, run)) + (c16 >> (16 - 2 * run));
+                            if (run == kmax) {
+                                const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                                is_top = true;
+                                if (((old >> ((b & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                            } else {
+                                atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                            }
+                        }
                     }
                     cA += __popcll(__ballot(up && c2 == 0));
                     cT += __popcll(__ballot(up && c2 == 1));
                     cG += __popcll(__ballot(up && c2 == 2));
                     cC += __popcll(__ballot(up && c2 == 3));
+                    nvalid += __popcll(__ballot(is_top));
                 }
                 if (lane == 0) {
                     if (cA) atomicAdd(&misc[M_UPA], cA);
                     if (cT) atomicAdd(&misc[M_UPT], cT);
                     if (cG) atomicAdd(&misc[M_UPG], cG);
                     if (cC) atomicAdd(&misc[M_UPC], cC);
+                    if (nvalid) atomicAdd(&misc[M_NVALID], nvalid);
                 }
             }
             __syncthreads();
@@ -279,14 +339,28 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             // N filter (L237-241 / L213): dropped when nn >= 0.3 * len, evaluated in double like CPython
             const bool keep = !(double(nn) >= 0.3 * double(n));
             uint32_t status = (jump ? ROW_JUMPBACK : 0u);
+            const uint32_t nvalid_top = misc[M_NVALID];
+            const int n_orph = K8 ? int(misc[M_NORPH]) : 0;
             if (tid == 0) {
                 P.seq_index[row] = dsi;
                 P.start[row] = rep_start;
                 P.stop[row] = rep_stop;
             }
+            auto code_at = [&](int it) -> uint32_t {
+                return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT) >> (16 - 2 * kmax);
+            };
+            auto cleanup = [&]() {      // representatives zero their max-mer bin; small tables cleared wholesale
+                if (K8) {
+                    for (int it = 0; it * NT < n; ++it)
+                        if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code_at(it)] = 0;
+                }
+                for (uint32_t i = tid; i < L.small_bytes / 16; i += NT)
+                    reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
+                if (tid < M_COUNT) misc[tid] = 0;
+            };
             if (!keep) {
                 __syncthreads();                    // everyone has read misc
-                if (tid < 4) misc[tid] = 0;
+                cleanup();
                 if (tid == 0) {
                     P.status[row] = status;
                     const double qnan = __longlong_as_double(0x7FF8000000000000LL);
@@ -297,54 +371,45 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 continue;
             }
 
-            // ---- phase 1: histogram every order; elect one representative per present max-mer --------
-            unsigned long long repmask = 0;
-            {
-                uint32_t nvalid = 0;
-                int it = 0;
-                for (int jj = tid; jj - lane < n; jj += NT, ++it) {
-                    bool is_top = false;
-                    if (jj < n) {
-                        const int64_t g = g0 + jj;
-                        const uint32_t c16 = fetch_codes16(P.codes, g);
-                        int run = lead_clear8(fetch_mask8(P.inv, g));       // window words are upper-cased: L334-335
-                        const int rem = n - jj;
-                        run = run < rem ? run : rem;
-                        run = run < kmax ? run : kmax;
-                        const int xs = run < ks ? run : ks;
-                        for (int x = kmin; x <= xs; ++x) {
-                            if (!K8 && x == kmax) break;                   // the top order is handled below
-                            const uint32_t b = uint32_t(table_offset(kmin, x)) + (c16 >> (16 - 2 * x));
-                            atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
-                        }
-                        if (K8) {
-                            if (run == 8) {
-                                const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
-                                is_top = true;
-                                if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
-                            } else if (run == 7 && kmin <= 7) {
-                                const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
-                                orph[slot] = uint16_t(c16 >> 2);
-                            }
-                        } else if (run == kmax) {
-                            const uint32_t b = uint32_t(table_offset(kmin, kmax)) + (c16 >> (16 - 2 * kmax));
-                            const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
-                            is_top = true;
-                            if (((old >> ((b & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
-                        }
-                    }
-                    nvalid += __popcll(__ballot(is_top));
+            // ---- marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] ------------------------
+            for (int x = ks - 1; x >= kmin; --x) {
+                const uint32_t ox = uint32_t(table_offset(kmin, x)), ou = uint32_t(table_offset(kmin, x + 1));
+                for (uint32_t c = tid; c < (1u << (2 * x)); c += NT) {
+                    const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ou + 4 * c);     // 8-byte aligned
+                    small16[ox + c] = uint16_t(small16[ox + c] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) +
+                                               (ch.y >> 16));
                 }
-                if (lane == 0 && nvalid) atomicAdd(&misc[M_NVALID], nvalid);
+                __syncthreads();
             }
-            __syncthreads();
 
             WinTables<K8> T;
             T.t8_32 = t8; T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
-            T.small32 = small32; T.small16 = reinterpret_cast<const uint16_t*>(small32);
-            T.orph = orph; T.n_orph = K8 ? int(misc[M_NORPH]) : 0;
+            T.small32 = small32; T.small16 = small16;
+            T.orph = orph; T.n_orph = n_orph;
             T.kmin = kmin; T.kmax = kmax;
-            const uint32_t nvalid_top = misc[M_NVALID];
+
+            // one recursion step (L399-446).  The first step needs no special case: W == wt gives a == 1.0 and
+            // 1.0*p + 0.0*0.0 == p exactly.
+            auto ivom_step = [&](int x, uint32_t cx, unsigned long long& W, double& I) {
+                const unsigned long long wt = (unsigned long long)cx << (2 * x);    // count * 4**x (L399-408)
+                W += wt;
+                const double p = double(cx) / double((S - (x - 1)) * 2);           // L401-409
+                const double a = double(wt) / double(W);                            // L437
+                I = a * p + ((1.0 - a) * I);                                        // L442-446
+            };
+
+            // ---- shared prefix: IVOM after order lv for every present lv-mer --------------------------------
+            if (lv) {
+                for (uint32_t c = tid; c < (1u << (2 * lv)); c += NT) {
+                    if (T.count(lv, c) == 0) continue;
+                    unsigned long long W = 0;
+                    double I = 0.0;
+                    for (int x = kmin; x <= lv; ++x) ivom_step(x, T.count(x, c >> (2 * (lv - x))), W, I);
+                    pre_i[c] = I;
+                    pre_w[c] = uint32_t(W);         // < 65536 * 4^6
+                }
+                __syncthreads();
+            }
 
             if (DEBUG && P.dbg_counts) {
                 uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
@@ -364,20 +429,20 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             Fix128 accw = {0, 0}, accg = {0, 0};
             bool zero_w = false;
             auto window_ivom = [&](uint32_t code) -> double {
+#if defined(FRISK_ABLATE) && (FRISK_ABLATE & 2)
+                return 1.0 / double(code + 1u + uint32_t(S));
+#endif
                 unsigned long long W = 0;
                 double I = 0.0;
-                for (int x = kmin; x <= kmax; ++x) {
-                    const uint32_t cx = T.count(x, code >> (2 * (kmax - x)));
-                    const unsigned long long wt = (unsigned long long)cx << (2 * x);    // count * 4**x (L399-408)
-                    W += wt;
-                    const double p = double(cx) / double((S - (x - 1)) * 2);           // L401-409
-                    const double a = double(wt) / double(W);                            // L437
-                    I = (x == kmin) ? a * p : a * p + ((1.0 - a) * I);                  // L442-446
+                int x0 = kmin;
+                if (lv) {
+                    const uint32_t pc = code >> (2 * (kmax - lv));
+                    W = pre_w[pc];
+                    I = pre_i[pc];
+                    x0 = lv + 1;
                 }
+                for (int x = x0; x <= kmax; ++x) ivom_step(x, T.count(x, code >> (2 * (kmax - x))), W, I);
                 return I;
-            };
-            auto code_at = [&](int it) -> uint32_t {
-                return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT) >> (16 - 2 * kmax);
             };
             if (ITS > 0) {
 #pragma unroll
@@ -414,6 +479,9 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             const double LN2 = 0.69314718055994530942;      // math.log(x, 2) == log(x) / log(2.0)
             auto term = [&](double Iw, double Ig) -> double {
                 if (!(Ig == Ig) || !(Iw == Iw)) return 0.0;          // zero-weight window: flagged, value unused
+#if defined(FRISK_ABLATE) && (FRISK_ABLATE & 4)
+                return Iw * Ig + Sw * Sg;
+#endif
                 const double pw = Iw / Sw;
                 const double pg = Ig / Sg;
                 return (pg != 0.0) ? pw * (log(pw / pg) / LN2) : 0.0;
@@ -445,13 +513,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             }
             __syncthreads();            // all reads of the tables are done
 
-            // ---- clean up: representatives zero their max-mer bin; small tables cleared wholesale ----------
-            if (K8) {
-                for (int it = 0; it * NT < n; ++it)
-                    if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code_at(it)] = 0;
-            }
-            for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
-            if (tid < M_COUNT) misc[tid] = 0;
+            cleanup();
             if (tid == 0) {
                 if (nvalid_top == 0) status |= ROW_NO_MAXMER;
                 // a zero divisor on the window side (L401-409) needs windowSpace in [kmin-1, kmax-1]
