@@ -526,21 +526,27 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     int64_t chunk = n / (int64_t(grid) * 8);
     chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, 16));
     P.chunk = int32_t(chunk);
-    const bool keep_regs = c->plan_maxwin <= 8 * FRISK_SCAN_NT;
+    // unroll depth of the per-position loops: the smallest instantiated ITS with ITS*1024 >= longest window
+    const int64_t need = (c->plan_maxwin + FRISK_SCAN_NT - 1) / FRISK_SCAN_NT;
+    const int its = need <= 2 ? 2 : need <= 5 ? 5 : need <= 8 ? 8 : 0;
 
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
+#define FRISK_LAUNCH(K8_, ITS_, DBG_) e = launch_scan<K8_, ITS_, DBG_>(P, grid, L.total, c->stream)
     if (k8) {
-        if (debug) e = keep_regs ? launch_scan<true, 8, true>(P, grid, L.total, c->stream)
-                                 : launch_scan<true, 0, true>(P, grid, L.total, c->stream);
-        else e = keep_regs ? launch_scan<true, 8, false>(P, grid, L.total, c->stream)
-                           : launch_scan<true, 0, false>(P, grid, L.total, c->stream);
+        if (debug) { if (its) FRISK_LAUNCH(true, 8, true); else FRISK_LAUNCH(true, 0, true); }
+        else if (its == 2) FRISK_LAUNCH(true, 2, false);
+        else if (its == 5) FRISK_LAUNCH(true, 5, false);
+        else if (its == 8) FRISK_LAUNCH(true, 8, false);
+        else FRISK_LAUNCH(true, 0, false);
     } else {
-        if (debug) e = keep_regs ? launch_scan<false, 8, true>(P, grid, L.total, c->stream)
-                                 : launch_scan<false, 0, true>(P, grid, L.total, c->stream);
-        else e = keep_regs ? launch_scan<false, 8, false>(P, grid, L.total, c->stream)
-                           : launch_scan<false, 0, false>(P, grid, L.total, c->stream);
+        if (debug) { if (its) FRISK_LAUNCH(false, 8, true); else FRISK_LAUNCH(false, 0, true); }
+        else if (its == 2) FRISK_LAUNCH(false, 2, false);
+        else if (its == 5) FRISK_LAUNCH(false, 5, false);
+        else if (its == 8) FRISK_LAUNCH(false, 8, false);
+        else FRISK_LAUNCH(false, 0, false);
     }
+#undef FRISK_LAUNCH
     HIPC(c, e);
     HIPC(c, hipEventRecord(c->ev1, c->stream));
 

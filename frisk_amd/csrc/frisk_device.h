@@ -27,8 +27,10 @@ struct ScafDesc {
 };
 
 // offset (in bins) of the order-x table inside a concatenation that starts at order kmin
+// = (4^x - 4^kmin) / 3 = sum_{i=kmin}^{x-1} 4^i: the bits 2i of 0b...0101 for kmin <= i < x (no division)
 __host__ __device__ inline int64_t table_offset(int kmin, int x) {
-    return ((int64_t(1) << (2 * x)) - (int64_t(1) << (2 * kmin))) / 3;
+    const uint64_t ones = 0x5555555555555555ull;
+    return int64_t((ones & ((uint64_t(1) << (2 * x)) - 1)) & ~((uint64_t(1) << (2 * kmin)) - 1));
 }
 
 // 16 bits = the 8 bases starting at padded position g (base g most significant)

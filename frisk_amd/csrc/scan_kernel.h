@@ -20,9 +20,16 @@
 // The IVOM value after order x depends only on the x-mer prefix, so the first five recursion steps are
 // evaluated once per present 5-mer (<= 1024 per window) into an LDS table and every representative continues
 // from there: 3 instead of 8 division-heavy steps per max-mer at K = 8, with bit-identical results.
+// With only 4 wavefronts per SIMD (the 128 KiB table allows one workgroup per CU) latency has to be hidden
+// inside each wavefront: the per-position loops are fully unrolled (ITS iterations, a template parameter),
+// loads and table gathers are unconditional and issued ahead of their use, and the recursion is evaluated
+// for every lane (non-representatives are masked out when accumulating) so that the compiler can interleave
+// the independent division chains of different positions.
 // FP64 throughout (the KLD sum cancels from O(1) terms to O(1e-2)); contraction off so that every
 // product/sum rounds exactly as CPython's does.  No MFMA: this is histogramming + a scalar recurrence.
 #pragma once
+#include <type_traits>
+
 #include "frisk_device.h"
 
 #define FRISK_SCAN_NT 1024
@@ -63,6 +70,22 @@ struct ScanParams {
 
 #pragma clang fp contract(off)
 
+// Diagnostic builds only (tools/ablate.py, -DFRISK_STOP=<n>): finish every window right after stage <n> with a
+// value that depends on the stage's results, to time the stages cumulatively.  Never in the product library.
+#ifdef FRISK_STOP
+#define STOP_AFTER(stage, value)                                                              \
+    if (FRISK_STOP == (stage)) {                                                              \
+        const double v_ = double(value);                                                      \
+        __syncthreads();                                                                      \
+        cleanup();                                                                            \
+        if (tid == 0) { P.status[row] = ROW_KEPT; P.kld[row] = v_; P.gc[row] = 0.5; }         \
+        __syncthreads();                                                                      \
+        continue;                                                                             \
+    }
+#else
+#define STOP_AFTER(stage, value)
+#endif
+
 // LDS carve-up (dynamic, all offsets multiples of 16 bytes)
 struct LdsLayout {
     uint32_t t8;        // byte offset of the order-8 table (K8 only)
@@ -71,12 +94,17 @@ struct LdsLayout {
     uint32_t orphans;   // u16 list
     uint32_t pre_i;     // f64[4^lv]: IVOM value after order lv, per lv-mer prefix
     uint32_t pre_w;     // u32[4^lv]: running weight sum after order lv
-    uint32_t misc;      // counters + reduction scratch
+    uint32_t ptab;      // f64[3][FRISK_PTAB]: c / ((S-(x-1))*2) for small counts c, orders above lv
+    uint32_t misc;      // 2 x 16 u32 counters (double-buffered by window parity) + reduction scratch
     uint32_t total;
 };
 
 // order at which the recursion is shared between max-mers (0 = not shared)
 __host__ __device__ inline int shared_level(int kmin, int kmax) { return (kmin <= 5 && kmax >= 6) ? 5 : 0; }
+
+#define FRISK_PTAB 64
+#define FRISK_MISC_SLOTS 16
+#define FRISK_MISC_BYTES (2 * FRISK_MISC_SLOTS * 4 + 2 * 16 * 4 * 8)   // counters x2, scratch x2 (16 waves x 2 x 128 bit)
 
 __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap) {
     LdsLayout L;
@@ -96,24 +124,24 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
     if (lv) o += (1u << (2 * lv)) * 8;
     L.pre_w = o;
     if (lv) o += (1u << (2 * lv)) * 4;
+    L.ptab = o;
+    if (lv) o += 3 * FRISK_PTAB * 8;
     L.misc = o;
-    o += 16 * 4 + 16 * 4 * 8 + 16;   // 16 u32 counters, 16 waves x 2 x 128-bit reduction scratch
+    o += FRISK_MISC_BYTES;
     L.total = (o + 15) / 16 * 16;
     return L;
 }
 
 // misc counter slots
-enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS, M_COUNT = 16 };
+enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS };
 
 template <bool K8>
 struct WinTables {
-    uint32_t* t8_32;         // order-8 table as dwords
     const uint16_t* t8_16;
-    uint32_t* small32;
     const uint16_t* small16;
     const uint16_t* orph;
     int n_orph;
-    int kmin, kmax;
+    int kmin;
 
     // count of the x-mer `c` in the current window
     __device__ inline uint32_t count(int x, uint32_t c) const {
@@ -143,9 +171,6 @@ struct Fix128 {
 };
 
 __device__ inline Fix128 fix_from_double(double x) {
-#if defined(FRISK_ABLATE) && (FRISK_ABLATE & 8)
-    Fix128 z; z.hi = (long long)__double_as_longlong(x); z.lo = 0; return z;
-#endif
     const double s = x * 0x1p40;            // exact scaling
     double f = floor(s);
     double r = s - f;                       // in [0, 1]; exactly 1.0 only for a tiny negative s
@@ -166,7 +191,23 @@ __device__ inline double fix_to_double(const Fix128& a) {
     return double(a.hi) * 0x1p-40 + double(a.lo) * 0x1p-104;
 }
 
-// sum two accumulators over the workgroup; every thread returns the same totals
+// n / d for operands whose quotient needs no exponent scaling (here: positive integers < 2^53 as doubles, and
+// ratios of normal probabilities): the same reciprocal refinement + residual correction the compiler emits for
+// an IEEE fdiv, without the v_div_scale / v_div_fmas / v_div_fixup range handling - bit-identical results for
+// these operands at two thirds of the instructions.
+__device__ inline double div_exact(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = n * r;
+    e = __builtin_fma(-d, q, n);
+    return __builtin_fma(e, r, q);
+}
+
+// sum two accumulators over the workgroup; every thread returns the same totals.  One barrier: the caller
+// alternates between two scratch areas, and a scratch area is rewritten only several barriers later.
 template <int NW>
 __device__ inline void block_sum2(Fix128& a, Fix128& b, unsigned long long* scratch, int tid) {
     for (int o = 32; o > 0; o >>= 1) {
@@ -176,7 +217,6 @@ __device__ inline void block_sum2(Fix128& a, Fix128& b, unsigned long long* scra
         fix_add(a, ta);
         fix_add(b, tb);
     }
-    __syncthreads();                       // scratch free (previous readers done)
     if ((tid & 63) == 0) {
         unsigned long long* p = scratch + (tid >> 6) * 4;
         p[0] = (unsigned long long)a.hi; p[1] = a.lo; p[2] = (unsigned long long)b.hi; p[3] = b.lo;
@@ -193,16 +233,19 @@ __device__ inline void block_sum2(Fix128& a, Fix128& b, unsigned long long* scra
     b = sb;
 }
 
-// ITS > 0: windows of at most ITS*NT positions keep their per-representative IVOM values in registers
-// between the two passes; ITS == 0: any length, values are recomputed in pass 2.
+// ITS > 0: the window has at most ITS*NT positions; per-position loops are fully unrolled and the per-position
+//          codes and IVOM values stay in registers between the passes.
+// ITS == 0: any length up to 65535; runtime loops, values recomputed in the last pass.
 template <bool K8, int ITS, bool DEBUG>
 __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P) {
     constexpr int NT = FRISK_SCAN_NT;
     constexpr int NW = NT / 64;
+    constexpr int NREG = ITS > 0 ? ITS : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int kmin = P.kmin, kmax = P.kmax;
+    const int kmin = P.kmin;
+    const int kmax = K8 ? 8 : P.kmax;                   // compile-time at K = 8: the order loops unroll
     const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap);
     uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L.t8);
     uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
@@ -210,15 +253,18 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
     uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L.orphans);
     double* pre_i = reinterpret_cast<double*>(lds + L.pre_i);
     uint32_t* pre_w = reinterpret_cast<uint32_t*>(lds + L.pre_w);
-    uint32_t* misc = reinterpret_cast<uint32_t*>(lds + L.misc);
-    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds + L.misc + M_COUNT * 4);
+    double* ptab = reinterpret_cast<double*>(lds + L.ptab);
+    using wsum_t = typename std::conditional<(ITS > 0), uint32_t, unsigned long long>::type;   // W < 2^32 for n <= 8192
+    uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L.misc);
+    unsigned long long* scratch_base = reinterpret_cast<unsigned long long*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
     const int ks = K8 ? 6 : kmax;                       // highest order kept in the small tables
     const int lv = shared_level(kmin, kmax);            // recursion shared up to this order (0: not shared)
+    const int kshift = 16 - 2 * kmax;
 
-    // one-time clear of the histograms
+    // one-time clear of the histograms and counters
     if (K8) for (int i = tid; i < FRISK_T8_BYTES / 16; i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
-    if (tid < M_COUNT) misc[tid] = 0;
+    if (tid < 2 * FRISK_MISC_SLOTS) misc_base[tid] = 0;
     __syncthreads();
 
     // XCD-aware work split: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
@@ -232,6 +278,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
     ScafDesc d;
     d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
     int dsi = -1;
+    uint32_t parity = 0;
 
     for (int64_t q = v; q < nchunks; q += G) {
         const int64_t cb = P.c0 + q * P.chunk;
@@ -271,28 +318,36 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             }
             const int64_t g0 = d.off + st;
             const int64_t row = cand - P.c0;
+            uint32_t* misc = misc_base + parity * FRISK_MISC_SLOTS;         // this window's counters
+            uint32_t* misc_other = misc_base + (parity ^ 1u) * FRISK_MISC_SLOTS;
+            parity ^= 1u;
 
-            // ---- phase 1: one pass over the window's positions ------------------------------------------
+            // ---- stage 1: one pass over the window's positions ------------------------------------------
             //   * uppercase base composition (calcGC L120-137, countN L106-118) by wave ballots
             //   * ONE small-table update per position + the max-mer update that elects representatives
             // (done before the N filter is known: 93 % of windows pass it, the others are cleaned up below)
             unsigned long long repmask = 0;
+            uint32_t c16v[NREG];
             {
                 uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
-                int it = 0;
-                for (int jj = tid; jj - lane < n; jj += NT, ++it) {
-                    bool is_top = false, up = false;
-                    uint32_t c2 = 0;
-                    if (jj < n) {
-                        const int64_t g = g0 + jj;
-                        const uint32_t c16 = fetch_codes16(P.codes, g);
-                        const uint32_t inv8 = fetch_mask8(P.inv, g);
-                        up = !((inv8 >> 7) | fetch_mask1(P.low, g));
-                        c2 = c16 >> 14;
-                        int run = lead_clear8(inv8);                         // window words are upper-cased: L334-335
-                        const int rem = n - jj;
-                        run = run < rem ? run : rem;
-                        run = run < kmax ? run : kmax;
+#pragma unroll
+                for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
+                    if (ITS > 0 && it * NT >= n) { c16v[it] = 0; continue; }  // wave-uniform: past the window
+                    const int jj = tid + it * NT;
+                    const bool act = jj < n;
+                    const int64_t g = g0 + (act ? jj : 0);                   // clamped: loads are unconditional
+                    const uint32_t c16 = fetch_codes16(P.codes, g);
+                    const uint32_t inv8 = fetch_mask8(P.inv, g);
+                    const uint32_t low1 = fetch_mask1(P.low, g);
+                    if (ITS > 0) c16v[it] = c16;
+                    const bool up = act && !((inv8 >> 7) | low1);
+                    const uint32_t c2 = c16 >> 14;
+                    int run = lead_clear8(inv8);                             // window words are upper-cased: L334-335
+                    const int rem = n - jj;
+                    run = run < rem ? run : rem;
+                    run = run < kmax ? run : kmax;
+                    bool is_top = false;
+                    if (act) {
                         if (K8) {
                             const int rs = run < 6 ? run : 6;
                             if (rs >= kmin) {
@@ -333,6 +388,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 }
             }
             __syncthreads();
+            if (tid < FRISK_MISC_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
             const uint32_t upA = misc[M_UPA], upT = misc[M_UPT], upG = misc[M_UPG], upC = misc[M_UPC];
             const int64_t S = int64_t(upA) + upT + upG + upC;       // windowSpace (L380)
             const int64_t nn = n - S;                               // nnTotal of the window
@@ -346,20 +402,23 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 P.start[row] = rep_start;
                 P.stop[row] = rep_stop;
             }
-            auto code_at = [&](int it) -> uint32_t {
-                return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT) >> (16 - 2 * kmax);
+            auto code16_at = [&](int it) -> uint32_t {
+                if (ITS > 0) return c16v[it];
+                return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT);
             };
-            auto cleanup = [&]() {      // representatives zero their max-mer bin; small tables cleared wholesale
-                if (K8) {
-                    for (int it = 0; it * NT < n; ++it)
-                        if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code_at(it)] = 0;
+            auto zero_own_bins = [&]() {        // representatives zero their max-mer bin (K8; the small tables are
+                if (K8) {                       // cleared wholesale)
+#pragma unroll
+                    for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it)
+                        if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code16_at(it)] = 0;
                 }
+            };
+            auto clear_small = [&]() {
                 for (uint32_t i = tid; i < L.small_bytes / 16; i += NT)
                     reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
-                if (tid < M_COUNT) misc[tid] = 0;
             };
+            auto cleanup = [&]() { zero_own_bins(); clear_small(); };
             if (!keep) {
-                __syncthreads();                    // everyone has read misc
                 cleanup();
                 if (tid == 0) {
                     P.status[row] = status;
@@ -370,46 +429,74 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 __syncthreads();
                 continue;
             }
+            STOP_AFTER(1, small16[tid & 3] + nvalid_top)
 
-            // ---- marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] ------------------------
-            for (int x = ks - 1; x >= kmin; --x) {
+            // ---- stage 2: marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] --------------
+            auto marg_level = [&](int x, int first, int step) {
                 const uint32_t ox = uint32_t(table_offset(kmin, x)), ou = uint32_t(table_offset(kmin, x + 1));
-                for (uint32_t c = tid; c < (1u << (2 * x)); c += NT) {
+                for (uint32_t c = first; c < (1u << (2 * x)); c += step) {
                     const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ou + 4 * c);     // 8-byte aligned
                     small16[ox + c] = uint16_t(small16[ox + c] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) +
                                                (ch.y >> 16));
                 }
-                __syncthreads();
+            };
+            {
+                int x = ks - 1;
+                for (; x >= kmin && x > 3; --x) {               // wide levels: all waves, one barrier each
+                    marg_level(x, tid, NT);
+                    __syncthreads();
+                }
+                if (x >= kmin) {                                // levels of <= 64 bins: wave 0 alone, in order
+                    if (tid < 64) {
+                        for (; x >= kmin; --x) {
+                            marg_level(x, tid, 64);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    __syncthreads();
+                }
             }
+            STOP_AFTER(2, small16[tid & 3] + nvalid_top)
 
             WinTables<K8> T;
-            T.t8_32 = t8; T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
-            T.small32 = small32; T.small16 = small16;
+            T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
+            T.small16 = small16;
             T.orph = orph; T.n_orph = n_orph;
-            T.kmin = kmin; T.kmax = kmax;
+            T.kmin = kmin;
 
             // one recursion step (L399-446).  The first step needs no special case: W == wt gives a == 1.0 and
             // 1.0*p + 0.0*0.0 == p exactly.
-            auto ivom_step = [&](int x, uint32_t cx, unsigned long long& W, double& I) {
-                const unsigned long long wt = (unsigned long long)cx << (2 * x);    // count * 4**x (L399-408)
+            auto ivom_step = [&](int x, uint32_t cx, wsum_t& W, double& I, double p) {
+                const wsum_t wt = wsum_t(cx) << (2 * x);                            // count * 4**x (L399-408)
                 W += wt;
-                const double p = double(cx) / double((S - (x - 1)) * 2);           // L401-409
-                const double a = double(wt) / double(W);                            // L437
+                const double a = div_exact(double(wt), double(W));                  // L437
                 I = a * p + ((1.0 - a) * I);                                        // L442-446
             };
+            auto prob = [&](int x, uint32_t cx) -> double {                         // L401-409
+                return div_exact(double(cx), double(int32_t((S - (x - 1)) * 2)));
+            };
 
-            // ---- shared prefix: IVOM after order lv for every present lv-mer --------------------------------
+            // ---- stage 3: shared prefix - IVOM after order lv for every present lv-mer ----------------------
             if (lv) {
                 for (uint32_t c = tid; c < (1u << (2 * lv)); c += NT) {
                     if (T.count(lv, c) == 0) continue;
-                    unsigned long long W = 0;
+                    wsum_t W = 0;
                     double I = 0.0;
-                    for (int x = kmin; x <= lv; ++x) ivom_step(x, T.count(x, c >> (2 * (lv - x))), W, I);
+                    for (int x = kmin; x <= lv; ++x) {
+                        const uint32_t cx = T.count(x, c >> (2 * (lv - x)));
+                        ivom_step(x, cx, W, I, prob(x, cx));
+                    }
                     pre_i[c] = I;
                     pre_w[c] = uint32_t(W);         // < 65536 * 4^6
                 }
+                // p = c / ((S-(x-1))*2) depends only on (x, c): tabulate it for the small counts that dominate
+                // the orders above lv (one division per entry instead of one per max-mer and order)
+                for (int e = tid; e < (kmax - lv) * FRISK_PTAB; e += NT)
+                    ptab[e] = prob(lv + 1 + e / FRISK_PTAB, uint32_t(e % FRISK_PTAB));
                 __syncthreads();
             }
+            STOP_AFTER(3, lv ? pre_i[tid & 1023] : 0.0)
 
             if (DEBUG && P.dbg_counts) {
                 uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
@@ -423,84 +510,6 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 P.dbg_meta[row * 3 + 1] = (n >= kmax ? n - kmax + 1 : 0) - int64_t(nvalid_top); // exMax (L344-345)
                 P.dbg_meta[row * 3 + 2] = nn;                                                  // nnTotal
             }
-
-            // ---- phase 2: IVOM of every present max-mer, window side (L394-450) and genome side (table) --
-            double iw_keep[ITS > 0 ? ITS : 1], ig_keep[ITS > 0 ? ITS : 1];
-            Fix128 accw = {0, 0}, accg = {0, 0};
-            bool zero_w = false;
-            auto window_ivom = [&](uint32_t code) -> double {
-#if defined(FRISK_ABLATE) && (FRISK_ABLATE & 2)
-                return 1.0 / double(code + 1u + uint32_t(S));
-#endif
-                unsigned long long W = 0;
-                double I = 0.0;
-                int x0 = kmin;
-                if (lv) {
-                    const uint32_t pc = code >> (2 * (kmax - lv));
-                    W = pre_w[pc];
-                    I = pre_i[pc];
-                    x0 = lv + 1;
-                }
-                for (int x = x0; x <= kmax; ++x) ivom_step(x, T.count(x, code >> (2 * (kmax - x))), W, I);
-                return I;
-            };
-            if (ITS > 0) {
-#pragma unroll
-                for (int it = 0; it < ITS; ++it) {
-                    iw_keep[it] = 0.0; ig_keep[it] = 0.0;
-                    if ((repmask >> it) & 1ull) {
-                        const uint32_t code = code_at(it);
-                        const double Iw = window_ivom(code);
-                        const double Ig = P.ig[code];
-                        zero_w |= (Ig != Ig);
-                        iw_keep[it] = Iw; ig_keep[it] = Ig;
-                        fix_add(accw, fix_from_double(Iw));
-                        if (Ig == Ig) fix_add(accg, fix_from_double(Ig));
-                    }
-                }
-            } else {
-                for (int it = 0; it * NT < n; ++it) {
-                    if ((repmask >> it) & 1ull) {
-                        const uint32_t code = code_at(it);
-                        const double Iw = window_ivom(code);
-                        const double Ig = P.ig[code];
-                        zero_w |= (Ig != Ig);
-                        fix_add(accw, fix_from_double(Iw));
-                        if (Ig == Ig) fix_add(accg, fix_from_double(Ig));
-                    }
-                }
-            }
-            if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
-            block_sum2<NW>(accw, accg, scratch, tid);       // sumWindowIVOM of both sides (L450)
-            const double Sw = fix_to_double(accw), Sg = fix_to_double(accg);
-
-            // ---- phase 3: normalise (L453-454) and accumulate the divergence (L465-470) ----------------
-            Fix128 acck = {0, 0}, unused = {0, 0};
-            const double LN2 = 0.69314718055994530942;      // math.log(x, 2) == log(x) / log(2.0)
-            auto term = [&](double Iw, double Ig) -> double {
-                if (!(Ig == Ig) || !(Iw == Iw)) return 0.0;          // zero-weight window: flagged, value unused
-#if defined(FRISK_ABLATE) && (FRISK_ABLATE & 4)
-                return Iw * Ig + Sw * Sg;
-#endif
-                const double pw = Iw / Sw;
-                const double pg = Ig / Sg;
-                return (pg != 0.0) ? pw * (log(pw / pg) / LN2) : 0.0;
-            };
-            if (ITS > 0) {
-#pragma unroll
-                for (int it = 0; it < ITS; ++it)
-                    if ((repmask >> it) & 1ull) fix_add(acck, fix_from_double(term(iw_keep[it], ig_keep[it])));
-            } else {
-                for (int it = 0; it * NT < n; ++it)
-                    if ((repmask >> it) & 1ull) {
-                        const uint32_t code = code_at(it);
-                        fix_add(acck, fix_from_double(term(window_ivom(code), P.ig[code])));
-                    }
-            }
-            block_sum2<NW>(acck, unused, scratch, tid);
-            const double acc = fix_to_double(acck);
-            const uint32_t flags_lds = misc[M_FLAGS];
-
             // RIP indices from the window's dinucleotide counts (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3
             double pi = 0, si = 0, cri = 0;
             if ((P.flags & 1u) && tid == 0) {
@@ -511,9 +520,79 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 si = (AC + GT) > 0 ? double(CA + TG) / double(AC + GT) : qnan;
                 cri = (pi == 0.0 || si == 0.0) ? qnan : pi - si;        // "if PI and SI" (L491): 0.0 is falsy
             }
-            __syncthreads();            // all reads of the tables are done
 
-            cleanup();
+            // ---- stage 4: IVOM of every max-mer position, window side (L394-450) and genome side (table) ----
+            // Evaluated for EVERY position of the lane (straight-line code: independent division chains of
+            // different positions interleave); only representatives are accumulated.
+            auto window_ivom = [&](uint32_t code) -> double {
+                wsum_t W = 0;
+                double I = 0.0;
+                if (lv) {
+                    constexpr int LV = 5;                                   // == shared_level() whenever it is not 0
+                    const uint32_t pc = code >> (2 * (kmax - LV));
+                    W = pre_w[pc];
+                    I = pre_i[pc];
+#pragma unroll
+                    for (int x = LV + 1; x <= kmax; ++x) {
+                        const uint32_t cx = T.count(x, code >> (2 * (kmax - x)));
+                        const double p = (cx < FRISK_PTAB) ? ptab[(x - LV - 1) * FRISK_PTAB + cx] : prob(x, cx);
+                        ivom_step(x, cx, W, I, p);
+                    }
+                } else {
+                    for (int x = kmin; x <= kmax; ++x) {
+                        const uint32_t cx = T.count(x, code >> (2 * (kmax - x)));
+                        ivom_step(x, cx, W, I, prob(x, cx));
+                    }
+                }
+                return I;
+            };
+            double iw_keep[NREG], ig_keep[NREG];
+            Fix128 accw = {0, 0}, accg = {0, 0};
+            bool zero_w = false;
+#pragma unroll
+            for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
+                if (ITS > 0 && it * NT >= n) { iw_keep[it] = 0.0; ig_keep[it] = 0.0; continue; }   // wave-uniform
+                const bool rep = (repmask >> it) & 1ull;
+                if (ITS == 0 && !rep) continue;
+                const uint32_t code = code16_at(it) >> kshift;
+                const double Ig = P.ig[code];                   // unconditional gather (code < 4^K always)
+                const double Iw = window_ivom(code);
+                zero_w |= rep && (Ig != Ig);
+                const double iw = rep ? Iw : 0.0, ig = (rep && Ig == Ig) ? Ig : 0.0;
+                if (ITS > 0) { iw_keep[it] = iw; ig_keep[it] = rep ? Ig : 0.0; }
+                fix_add(accw, fix_from_double(iw));
+                fix_add(accg, fix_from_double(ig));
+            }
+            if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
+            block_sum2<NW>(accw, accg, scratch_base, tid);          // sumWindowIVOM of both sides (L450)
+            const double Sw = fix_to_double(accw), Sg = fix_to_double(accg);
+            STOP_AFTER(4, Sw + Sg)
+
+            // ---- stage 5: normalise (L453-454), accumulate the divergence (L465-470), re-zero own bins -------
+            Fix128 acck = {0, 0}, unused = {0, 0};
+            const double LN2 = 0.69314718055994530942;      // math.log(x, 2) == log(x) / log(2.0)
+#pragma unroll
+            for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
+                if (ITS > 0 && it * NT >= n) continue;
+                const bool rep = (repmask >> it) & 1ull;
+                if (ITS == 0 && !rep) continue;
+                double Iw, Ig;
+                if (ITS > 0) { Iw = iw_keep[it]; Ig = ig_keep[it]; }
+                else { const uint32_t code = code16_at(it) >> kshift; Iw = window_ivom(code); Ig = P.ig[code]; }
+                const double pw = div_exact(Iw, Sw);                        // L453-454
+                const double pg = div_exact(Ig, Sg);
+                const double t = pw * (log(div_exact(pw, pg)) / LN2);       // L470
+                // skipped terms: non-representatives, zero-weight max-mers (window flagged), and Pg == 0 (L469)
+                const bool use = rep && (Ig == Ig) && (Iw == Iw) && (pg != 0.0);
+                fix_add(acck, fix_from_double(use ? t : 0.0));
+            }
+            if (ITS == 0) __syncthreads();                  // the generic path re-read the tables just now
+            const uint32_t flags_lds = misc[M_FLAGS];
+            zero_own_bins();                                // nobody reads the max-mer table any more
+            block_sum2<NW>(acck, unused, scratch_base + NW * 4, tid);
+            const double acc = fix_to_double(acck);
+
+            clear_small();                                  // all reads of the small tables are behind the barrier
             if (tid == 0) {
                 if (nvalid_top == 0) status |= ROW_NO_MAXMER;
                 // a zero divisor on the window side (L401-409) needs windowSpace in [kmin-1, kmax-1]

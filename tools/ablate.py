@@ -38,6 +38,10 @@ def main():
         env = dict(os.environ, FRISK_HIP_LIB=lib)
         out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, scale)], env=env, capture_output=True, text=True)
         print(spec, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:], flush=True)
+        for line in out.stderr.splitlines():
+            if line.startswith("[stamps]"):
+                print("   ", line, flush=True)
+                break
 
 
 if __name__ == "__main__":
