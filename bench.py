@@ -97,7 +97,7 @@ def main():
         t_prof = eng.kernel_ms(1)
         eng.profile_allreduce()
         eng.profile_finalize()
-        res = eng.scan(W, INC)
+        res = eng.scan(W, INC, pinned=True)
         return res, t_prof, eng.kernel_ms(0)
 
     def fence():

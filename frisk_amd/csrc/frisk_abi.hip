@@ -238,6 +238,16 @@ const char* frisk_last_error(const frisk_ctx* c) { return c ? c->err.c_str() : "
 int64_t frisk_profile_len(const frisk_ctx* c) { return c ? c->nprof : 0; }
 int64_t frisk_profile_raw_len(const frisk_ctx* c) { return c ? c->nprof + 4 : 0; }
 int64_t frisk_seq_padded_len(const frisk_ctx* c) { return (c && c->have_seq) ? c->padded_len : 0; }
+void* frisk_host_alloc(frisk_ctx* c, int64_t bytes) {
+    if (!c || bytes <= 0) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, size_t(bytes), hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+void frisk_host_free(frisk_ctx* c, void* ptr) {
+    if (c && ptr) { (void)hipSetDevice(c->device); (void)hipHostFree(ptr); }
+}
 double frisk_last_kernel_ms(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 3) ? c->ms[which] : -1.0; }
 
 // ------------------------------------------------------------------------------------- sequences

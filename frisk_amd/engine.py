@@ -55,12 +55,32 @@ class Engine:
         self.nprof = int(self._lib.frisk_profile_len(self._ctx))
         self.n_seq = 0
         self.seq_lens = []
+        self._pinned = {}           # name -> (address, nbytes): page-locked result buffers, reused across scans
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if getattr(self, "_ctx", None):
+            for addr, _ in self._pinned.values():
+                self._lib.frisk_host_free(self._ctx, C.c_void_p(addr))
+            self._pinned = {}
             self._lib.frisk_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def _pinned_array(self, name, n, dtype):
+        """numpy view of a page-locked buffer owned by this engine (grown on demand, reused between calls)."""
+        dtype = np.dtype(dtype)
+        need = max(int(n), 1) * dtype.itemsize
+        addr, have = self._pinned.get(name, (0, 0))
+        if have < need:
+            if addr:
+                self._lib.frisk_host_free(self._ctx, C.c_void_p(addr))
+            cap = need + need // 8
+            addr = self._lib.frisk_host_alloc(self._ctx, cap)
+            if not addr:
+                raise MemoryError("frisk_host_alloc(%d) failed" % cap)
+            self._pinned[name] = (addr, cap)
+        buf = (C.c_char * need).from_address(addr)
+        return np.frombuffer(buf, dtype=dtype, count=max(int(n), 1))
 
     def __del__(self):
         try:
@@ -170,18 +190,25 @@ class Engine:
         self._check(self._lib.frisk_scan_plan(self._ctx, int(w), int(inc), flags, C.byref(n)))
         return int(n.value)
 
-    def scan(self, w, inc, rip=False, scaffolds_all=False, c0=0, c1=-1, debug=False):
+    def scan(self, w, inc, rip=False, scaffolds_all=False, c0=0, c1=-1, debug=False, pinned=False):
+        """Score candidates [c0, c1).  With pinned=True the result arrays are views of page-locked buffers owned
+        by the engine: D2H at PCIe rate and no per-call allocation, but the views are only valid until the next
+        scan() on this engine.  pinned=False (default) returns ordinary numpy arrays."""
         flags = (_ffi.SCAN_RIP if rip else 0) | (_ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0)
         total = self.scan_plan(w, inc, scaffolds_all)
         if c1 < 0:
             c1 = total
         n = max(c1 - c0, 0)
         cap = max(n, 1)
+        if pinned and not debug:
+            new = lambda name, dt: self._pinned_array(name, cap, dt)       # noqa: E731
+        else:
+            new = lambda name, dt: np.zeros(cap, dt)                       # noqa: E731
         r = ScanResult(
-            seq_index=np.zeros(cap, np.int32), start=np.zeros(cap, np.int64), stop=np.zeros(cap, np.int64),
-            status=np.zeros(cap, np.uint32), kld=np.zeros(cap, np.float64), gc=np.zeros(cap, np.float64),
-            pi=np.zeros(cap, np.float64) if rip else None, si=np.zeros(cap, np.float64) if rip else None,
-            cri=np.zeros(cap, np.float64) if rip else None,
+            seq_index=new("seq", np.int32), start=new("start", np.int64), stop=new("stop", np.int64),
+            status=new("status", np.uint32), kld=new("kld", np.float64), gc=new("gc", np.float64),
+            pi=new("pi", np.float64) if rip else None, si=new("si", np.float64) if rip else None,
+            cri=new("cri", np.float64) if rip else None,
             counts=np.zeros((cap, self.nprof), np.uint32) if debug else None,
             meta=np.zeros((cap, 3), np.int64) if debug else None)
         self._check(self._lib.frisk_scan(self._ctx, int(w), int(inc), flags, int(c0), int(c1), cap,

@@ -94,7 +94,7 @@ class HotPath:
         if rip and args.maxWordSize < 2:
             raise ValueError("2 is not in list")        # range(m, K+1).index(2), reference L478
         res = self.engine.scan(args.windowlen, args.increment, rip=rip,
-                               scaffolds_all=bool(getattr(args, "scaffoldsAll", False)), debug=debug)
+                               scaffolds_all=bool(getattr(args, "scaffoldsAll", False)), debug=debug, pinned=not debug)
         kept = np.nonzero(res.kept)[0]
         bad = kept[(res.status[kept] & _ffi.ROW_ZERO_WEIGHT) != 0]
         rows = []

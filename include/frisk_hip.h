@@ -115,6 +115,11 @@ int frisk_scan(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int64_t c
                double* kld, double* gc, double* pi, double* si, double* cri,
                uint32_t* dbg_counts, int64_t* dbg_meta);
 
+/* Page-locked host memory for result buffers: D2H copies into it are asynchronous and run at PCIe rate
+ * (pageable buffers work too, at a fraction of it).  Free with frisk_host_free before frisk_destroy. */
+void* frisk_host_alloc(frisk_ctx* ctx, int64_t bytes);
+void  frisk_host_free(frisk_ctx* ctx, void* ptr);
+
 /* Timing of the most recent launches on the context's stream, measured with HIP events:
  * which = 0 scan kernel, 1 profile_add kernel, 2 pack kernel.  Returns milliseconds, <0 if none. */
 double frisk_last_kernel_ms(const frisk_ctx* ctx, int which);
