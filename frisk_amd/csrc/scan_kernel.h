@@ -141,6 +141,7 @@ struct WinTables {
     const uint16_t* small16;
     const uint16_t* orph;
     int n_orph;
+    uint32_t o0, o1, o2, o3;     // the first four orphan 7-mers (0xFFFFFFFF = none), wave-uniform
     int kmin;
 
     // count of the x-mer `c` in the current window
@@ -150,7 +151,9 @@ struct WinTables {
             if (x == 7) {
                 const uint2 q = *reinterpret_cast<const uint2*>(t8_16 + 4 * c);   // 4 children, 8-byte aligned
                 uint32_t s = (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16);
-                for (int o = 0; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
+                // orphans: a window has one (its tail) plus one per invalid run - almost always <= 4
+                s += (c == o0 ? 1u : 0u) + (c == o1 ? 1u : 0u) + (c == o2 ? 1u : 0u) + (c == o3 ? 1u : 0u);
+                for (int o = 4; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
                 return s;
             }
         }
@@ -158,37 +161,64 @@ struct WinTables {
     }
 };
 
+// natural logarithm of a positive normal double, < 1 ulp: the classic reduction x = 2^k * (1+f),
+// sqrt(2)/2 < 1+f < sqrt(2), log(1+f) = f - f^2/2 + s*(f^2/2 + R(s^2)), s = f/(2+f), with the degree-14 minimax
+// polynomial R of fdlibm's e_log.c (Sun Microsystems, freely distributable constants).  A third of the
+// instructions of the device library's log; the argument here is a ratio of probabilities.
+__device__ inline double div_exact(double n, double d);
+__device__ inline double log_pos(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int k = __builtin_amdgcn_frexp_exp(x);              // x = m * 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lowhalf = m < 0.70710678118654752440;
+    m = lowhalf ? m * 2.0 : m;
+    k = lowhalf ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = div_exact(f, 2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = double(k);
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
 // ---- order-independent summation ---------------------------------------------------------------------
 // Which lane becomes the representative of a max-mer depends on the arrival order of LDS atomics, so a
 // floating-point sum over representatives would depend on timing.  Every per-window sum (the two IVOM
-// normalisers and the divergence) is therefore accumulated in 128-bit fixed point (hi: units of 2^-40,
-// lo: units of 2^-104).  An un-normalised IVOM value is < 1 and a window has < 2^16 max-mers, so sums stay
-// below 2^16 << 2^23; every double >= 2^-51 converts exactly, smaller ones are truncated at 2^-104.
+// normalisers and the divergence) is therefore accumulated as a 128-bit two's-complement integer in units of
+// 2^-84 (four 32-bit limbs).  |term| < 2^11 and a window has < 2^16 max-mers, so |sum| < 2^27 * 2^84 < 2^127.
+// A term is cut into three 32-bit limbs (bits 2^-84 .. 2^11): 12 instructions, exact for every double whose
+// last mantissa bit is >= 2^-84, truncated below that (a fixed, order-independent function of the term).
 // Integer addition is associative, so results are bit-identical across runs, builds, grids and GPUs.
-struct Fix128 {
-    long long hi;               // units of 2^-40
-    unsigned long long lo;      // units of 2^-104
-};
+typedef __int128 Fix128;        // units of 2^-84
 
-__device__ inline Fix128 fix_from_double(double x) {
-    const double s = x * 0x1p40;            // exact scaling
-    double f = floor(s);
-    double r = s - f;                       // in [0, 1]; exactly 1.0 only for a tiny negative s
-    if (r >= 1.0) { f += 1.0; r = 0.0; }
-    Fix128 q;
-    q.hi = (long long)f;
-    q.lo = (unsigned long long)(r * 0x1p64);
-    return q;
+// the three 32-bit limbs of m >= 0 (bits 2^11 .. 2^-84), as one 96-bit integer
+__device__ inline Fix128 to_fix(double m) {
+    const double s1 = m * 0x1p20;                           // exact scalings and remainders
+    const uint32_t a1 = uint32_t(s1);                       // truncation = floor (m >= 0)
+    const double s2 = (s1 - double(a1)) * 0x1p32;
+    const uint32_t a2 = uint32_t(s2);
+    const double s3 = (s2 - double(a2)) * 0x1p32;
+    const uint32_t a3 = uint32_t(s3);
+    return (Fix128(a1) << 64) | Fix128((uint64_t(a2) << 32) | a3);
 }
 
-__device__ inline void fix_add(Fix128& a, const Fix128& b) {
-    const unsigned long long lo = a.lo + b.lo;
-    a.hi += b.hi + (lo < a.lo ? 1 : 0);
-    a.lo = lo;
+__device__ inline double fix_to_double(Fix128 a) {
+    const uint32_t l3 = uint32_t(a), l2 = uint32_t(a >> 32), l1 = uint32_t(a >> 64);
+    const int32_t hi = int32_t(a >> 96);
+    return ((double(l3) * 0x1p-84 + double(l2) * 0x1p-52) + double(l1) * 0x1p-20) + double(hi) * 0x1p12;
 }
 
-__device__ inline double fix_to_double(const Fix128& a) {
-    return double(a.hi) * 0x1p-40 + double(a.lo) * 0x1p-104;
+__device__ inline Fix128 fix_shfl_down(Fix128 a, int o) {
+    const uint64_t lo = __shfl_down((unsigned long long)uint64_t(a), o);
+    const uint64_t hi = __shfl_down((unsigned long long)uint64_t(a >> 64), o);
+    return Fix128((unsigned __int128)lo | ((unsigned __int128)hi << 64));
 }
 
 // n / d for operands whose quotient needs no exponent scaling (here: positive integers < 2^53 as doubles, and
@@ -209,25 +239,21 @@ __device__ inline double div_exact(double n, double d) {
 // sum two accumulators over the workgroup; every thread returns the same totals.  One barrier: the caller
 // alternates between two scratch areas, and a scratch area is rewritten only several barriers later.
 template <int NW>
-__device__ inline void block_sum2(Fix128& a, Fix128& b, unsigned long long* scratch, int tid) {
+__device__ inline void block_sum2(Fix128& a, Fix128& b, uint64_t* scratch, int tid) {
     for (int o = 32; o > 0; o >>= 1) {
-        Fix128 ta, tb;
-        ta.hi = __shfl_down(a.hi, o); ta.lo = __shfl_down(a.lo, o);
-        tb.hi = __shfl_down(b.hi, o); tb.lo = __shfl_down(b.lo, o);
-        fix_add(a, ta);
-        fix_add(b, tb);
+        a += fix_shfl_down(a, o);
+        b += fix_shfl_down(b, o);
     }
     if ((tid & 63) == 0) {
-        unsigned long long* p = scratch + (tid >> 6) * 4;
-        p[0] = (unsigned long long)a.hi; p[1] = a.lo; p[2] = (unsigned long long)b.hi; p[3] = b.lo;
+        uint64_t* p = scratch + (tid >> 6) * 4;
+        p[0] = uint64_t(a); p[1] = uint64_t(a >> 64); p[2] = uint64_t(b); p[3] = uint64_t(b >> 64);
     }
     __syncthreads();
-    Fix128 sa = {0, 0}, sb = {0, 0};
+    Fix128 sa = 0, sb = 0;
     for (int w = 0; w < NW; ++w) {
-        const unsigned long long* p = scratch + w * 4;
-        Fix128 ta = {(long long)p[0], p[1]}, tb = {(long long)p[2], p[3]};
-        fix_add(sa, ta);
-        fix_add(sb, tb);
+        const uint64_t* p = scratch + w * 4;
+        sa += Fix128((unsigned __int128)p[0] | ((unsigned __int128)p[1] << 64));
+        sb += Fix128((unsigned __int128)p[2] | ((unsigned __int128)p[3] << 64));
     }
     a = sa;
     b = sb;
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
     double* ptab = reinterpret_cast<double*>(lds + L.ptab);
     using wsum_t = typename std::conditional<(ITS > 0), uint32_t, unsigned long long>::type;   // W < 2^32 for n <= 8192
     uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L.misc);
-    unsigned long long* scratch_base = reinterpret_cast<unsigned long long*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
+    uint64_t* scratch_base = reinterpret_cast<uint64_t*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
     const int ks = K8 ? 6 : kmax;                       // highest order kept in the small tables
     const int lv = shared_level(kmin, kmax);            // recursion shared up to this order (0: not shared)
     const int kshift = 16 - 2 * kmax;
@@ -463,6 +489,13 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
             T.small16 = small16;
             T.orph = orph; T.n_orph = n_orph;
+            T.o0 = T.o1 = T.o2 = T.o3 = 0xFFFFFFFFu;
+            if (K8) {           // uniform loads (same address in every lane) made scalar
+                if (n_orph > 0) T.o0 = __builtin_amdgcn_readfirstlane(uint32_t(orph[0]));
+                if (n_orph > 1) T.o1 = __builtin_amdgcn_readfirstlane(uint32_t(orph[1]));
+                if (n_orph > 2) T.o2 = __builtin_amdgcn_readfirstlane(uint32_t(orph[2]));
+                if (n_orph > 3) T.o3 = __builtin_amdgcn_readfirstlane(uint32_t(orph[3]));
+            }
             T.kmin = kmin;
 
             // one recursion step (L399-446).  The first step needs no special case: W == wt gives a == 1.0 and
@@ -547,7 +580,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 return I;
             };
             double iw_keep[NREG], ig_keep[NREG];
-            Fix128 accw = {0, 0}, accg = {0, 0};
+            Fix128 accw = 0, accg = 0;
             bool zero_w = false;
 #pragma unroll
             for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
@@ -560,8 +593,8 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 zero_w |= rep && (Ig != Ig);
                 const double iw = rep ? Iw : 0.0, ig = (rep && Ig == Ig) ? Ig : 0.0;
                 if (ITS > 0) { iw_keep[it] = iw; ig_keep[it] = rep ? Ig : 0.0; }
-                fix_add(accw, fix_from_double(iw));
-                fix_add(accg, fix_from_double(ig));
+                accw += to_fix(iw);
+                accg += to_fix(ig);
             }
             if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
             block_sum2<NW>(accw, accg, scratch_base, tid);          // sumWindowIVOM of both sides (L450)
@@ -569,7 +602,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             STOP_AFTER(4, Sw + Sg)
 
             // ---- stage 5: normalise (L453-454), accumulate the divergence (L465-470), re-zero own bins -------
-            Fix128 acck = {0, 0}, unused = {0, 0};
+            Fix128 acck = 0, accn = 0;
             const double LN2 = 0.69314718055994530942;      // math.log(x, 2) == log(x) / log(2.0)
 #pragma unroll
             for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
@@ -581,15 +614,16 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 else { const uint32_t code = code16_at(it) >> kshift; Iw = window_ivom(code); Ig = P.ig[code]; }
                 const double pw = div_exact(Iw, Sw);                        // L453-454
                 const double pg = div_exact(Ig, Sg);
-                const double t = pw * (log(div_exact(pw, pg)) / LN2);       // L470
+                const double t = pw * div_exact(log_pos(div_exact(pw, pg)), LN2);   // L470
                 // skipped terms: non-representatives, zero-weight max-mers (window flagged), and Pg == 0 (L469)
                 const bool use = rep && (Ig == Ig) && (Iw == Iw) && (pg != 0.0);
-                fix_add(acck, fix_from_double(use ? t : 0.0));
+                const Fix128 tq = to_fix(fabs(use ? t : 0.0));
+                acck += (t < 0.0) ? -tq : tq;
             }
             if (ITS == 0) __syncthreads();                  // the generic path re-read the tables just now
             const uint32_t flags_lds = misc[M_FLAGS];
             zero_own_bins();                                // nobody reads the max-mer table any more
-            block_sum2<NW>(acck, unused, scratch_base + NW * 4, tid);
+            block_sum2<NW>(acck, accn, scratch_base + NW * 4, tid);
             const double acc = fix_to_double(acck);
 
             clear_small();                                  // all reads of the small tables are behind the barrier
