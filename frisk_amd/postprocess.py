@@ -1,0 +1,196 @@
+"""Host-side post-processing of the window table: thresholds on log10(KLD),
+interval merging, GFF3 writers.  numpy/pandas on <= millions of floats - no kernels here.
+
+Reference counterparts (frisk/__init__.py): FDBins L508-513, otsu L515-543, setKLDThresh L664-690,
+thresholdKLD L647-662, anomaly2GFF L553-567, thresholdRIP L692-720, RIP2GFF L577-587, natural_sort L85-89.
+The reference delegates interval merging to the external `bedtools` binary through pybedtools
+(`merge -d D -c 4,4,4 -o max,min,mean`, `window -w 0 -u`), which is not available here: `merge_intervals`
+restates the documented bedtools semantics (sorted input; features whose gap is <= D are merged, so
+book-ended features merge at D = 0; numeric summaries printed with bedtools' default precision `-prec 5`).
+Parity for that part is pinned by construction and by tests only, not by the reference's own output.
+"""
+import math
+import re
+
+import numpy as np
+
+FRISK_VERSION = "0+unknown"      # what the reference's versioneer reports outside a git checkout (_version.py)
+
+
+# ------------------------------------------------------------------------------------ number -> text
+def py2_str(x):
+    """str() of a value as Python 2 prints it (the reference is Python 2): floats carry 12 significant
+    digits ('%.12g', with '.0' appended to integral values); ints and strings are unchanged."""
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x:
+            return "nan"
+        if x in (float("inf"), float("-inf")):
+            return "inf" if x > 0 else "-inf"
+        s = "%.12g" % x
+        if "." not in s and "e" not in s:
+            s += ".0"
+        return s
+    return str(x)
+
+
+def py3_str(x):
+    if isinstance(x, (float, np.floating)):
+        return repr(float(x))
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    return str(x)
+
+
+def natural_sort(items, key=str):
+    """Scaffold-name order for the RIP GFF: digit runs compare as numbers, text case-insensitively (L85-89)."""
+    def parts(item):
+        return [int(t) if t.isdigit() else t.lower() for t in re.split("([0-9]+)", key(item))]
+    return sorted(items, key=parts)
+
+
+# ------------------------------------------------------------------------------------ thresholds
+def FDBins(data):
+    """Freedman-Diaconis-style bin count as the reference computes it: round(2 * IQR * n^(1/3)) (L508-513)."""
+    q75, q25 = np.percentile(data, [75, 25])
+    return int(round(2 * (q75 - q25) * math.pow(len(data), 1.0 / 3.0)))
+
+
+def otsu(data, optBins):
+    """Otsu split of the log10(KLD) histogram, restated from L515-543: the values are scaled by
+    -1/max|x| (so they become positive), binned into optBins bins normalised to the tallest bin, and the
+    split i in 1..optBins-1 minimising v1*q1 + v2*q2 (variances and masses of the bin heights on either
+    side) is mapped back to log10(KLD) through the histogram's bin edge."""
+    raw = data
+    x = np.atleast_1d(data)
+    x = x[~np.isnan(x)]
+    scale = max(abs(x)) * -1.0
+    x = x / scale
+    hist, edges = np.histogram(x, bins=optBins)
+    h = hist * 1.0
+    h = h.ravel() / h.max()
+    cum = h.cumsum()
+    best, thresh = np.inf, -1
+    for i in range(1, optBins):
+        left, right = h[:i], h[i:]
+        q1, q2 = cum[i - 1], cum[optBins - 1] - cum[i - 1]
+        m1, m2 = q1 / len(left), q2 / len(right)
+        v1 = np.sum(np.square(left - m1)) / len(left)
+        v2 = np.sum(np.square(right - m2)) / len(right)
+        score = (v1 * q1) + (v2 * q2)
+        if score < best:
+            best, thresh = score, i
+    return edges[thresh] * max(abs(raw)) * -1.0
+
+
+def setKLDThresh(args, logKLD):
+    """(threshold on log10(KLD), number of histogram bins) - L664-690.  Like the reference this needs one of
+    --forceThresholdKLD / --threshTypeKLD; without either the reference dies with UnboundLocalError."""
+    optBins = max(FDBins(logKLD), 30)
+    if args.forceThresholdKLD:
+        return np.log10(float(args.forceThresholdKLD)), optBins
+    if args.threshTypeKLD == "otsu":
+        return otsu(logKLD, optBins), optBins
+    if args.threshTypeKLD == "percentile":
+        return np.percentile(logKLD, args.percentileKLD), optBins
+    raise UnboundLocalError("local variable 'KLDthreshold' referenced before assignment "
+                            "(give --forceThresholdKLD or --threshTypeKLD, as with the reference)")
+
+
+# ------------------------------------------------------------------------------------ interval merging
+def _prec5(v):
+    return "%.5g" % v           # bedtools -prec default
+
+
+def merge_intervals(records, dist=0, ops=("max",), cols=(3,)):
+    """bedtools-merge semantics on records (chrom, start, end, v3, v4, ...) ALREADY sorted by chrom, start:
+    consecutive features on one chrom whose start - running_end <= dist are merged.  Returns tuples
+    (chrom, start, end, summary...) with one summary per (op, col) pair, formatted like bedtools (-prec 5)."""
+    out = []
+    cur = None
+    for rec in records:
+        chrom, start, end = rec[0], int(rec[1]), int(rec[2])
+        if cur is not None and chrom == cur[0] and start - cur[2] <= dist:
+            cur[2] = max(cur[2], end)
+            cur[3].append(rec)
+        else:
+            if cur is not None:
+                out.append(cur)
+            cur = [chrom, start, end, [rec]]
+    if cur is not None:
+        out.append(cur)
+    merged = []
+    for chrom, start, end, members in out:
+        summary = []
+        for op, col in zip(ops, cols):
+            vals = np.array([float(m[col]) for m in members], dtype=float)
+            v = {"max": vals.max, "min": vals.min, "mean": vals.mean}[op]()
+            summary.append(_prec5(v))
+        merged.append((chrom, start, end) + tuple(summary))
+    return merged
+
+
+def thresholdKLD(table, threshold, args, merge=True):
+    """Windows whose log10(KLD) is >= threshold (<= with --findSelf), sorted by (name, start, stop), merged with
+    `-d mergeDist -c 4,4,4 -o max,min,mean` (L647-662).  table: list of rows (name, start, stop, KLD, ...).
+    Returns (features, selected_rows)."""
+    rows = [r for r in table if not (isinstance(r[3], float) and r[3] != r[3])]
+    rows.sort(key=lambda r: (r[0], r[1], r[2]))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        logs = np.log10(np.array([float(r[3]) for r in rows], dtype=float)) if rows else np.zeros(0)
+    pick = (logs <= threshold) if getattr(args, "findSelf", False) else (logs >= threshold)
+    chosen = [r for r, p in zip(rows, pick) if p]
+    recs = [(r[0], int(r[1]), int(r[2]), float(r[3])) for r in chosen]
+    if merge:
+        feats = merge_intervals(recs, dist=getattr(args, "mergeDist", 0), ops=("max", "min", "mean"), cols=(3, 3, 3))
+    else:
+        feats = [(c, s, e, str(v)) for c, s, e, v in recs]
+    return feats, chosen
+
+
+def anomaly2GFF(features, args, category="Kmer-anomaly", version=FRISK_VERSION):
+    """GFF3 lines for merged anomalies (L553-567): source frisk_<version>, ID zero-padded to the width of the
+    feature count, KLD=<max> (or max/min/mean with --dimReduce features)."""
+    width = len(str(len(features)))
+    for n, f in enumerate(features, 1):
+        if getattr(args, "dimReduce", "windows") == "windows":
+            attrs = ["ID=Anomaly_" + str(n).zfill(width), "KLD=" + str(f[3])]
+        else:
+            attrs = ["ID=Anomaly_" + str(n).zfill(width), "maxKLD=" + str(f[3]), "minKLD=" + str(f[4]), "meanKLD=" + str(f[5])]
+        if n == 1:
+            yield "##gff-version 3\n"
+        yield "\t".join([str(f[0]), "frisk_" + version, category, str(f[1]), str(f[2]), ".", "+", ".", ";".join(attrs)]) + "\n"
+
+
+def thresholdRIP(table, args):
+    """RIP features (L692-720): windows with PI >= minPI, SI <= maxSI, CRI >= minCRI are merged
+    (`-d 0 -c 4,5,6,7,7 -o max,min,max,min,max`) and kept if they overlap at least one window with
+    CRI >= peakCRI (`window -w 0 -u`).  table rows: (name, start, stop, KLD, GC, PI, SI, CRI)."""
+    ok = [r for r in table if not any(isinstance(v, float) and v != v for v in (r[3], r[5], r[6], r[7]))]
+    ok.sort(key=lambda r: (r[0], r[1], r[2]))
+    basic = [r for r in ok if r[5] >= args.minPI and r[6] <= args.maxSI and r[7] >= args.minCRI]
+    peaks = [r for r in ok if r[7] >= args.peakCRI]
+    if not basic or not peaks:
+        return None
+    recs = [(r[0], int(r[1]), int(r[2]), r[3], r[5], r[6], r[7]) for r in basic]
+    merged = merge_intervals(recs, dist=0, ops=("max", "min", "max", "min", "max"), cols=(3, 4, 5, 6, 6))
+    keep = []
+    for f in merged:
+        # bedtools window -w 0: A and B overlap (half-open BED arithmetic on the given coordinates)
+        if any(p[0] == f[0] and int(p[1]) < f[2] and int(p[2]) > f[1] for p in peaks):
+            keep.append(f)
+    return keep or None
+
+
+def RIP2GFF(features, version=FRISK_VERSION):
+    """GFF3 lines for RIP features in natural scaffold order (L577-587)."""
+    feats = natural_sort(features, key=lambda f: f[0])
+    width = len(str(len(feats)))
+    for n, f in enumerate(feats, 1):
+        attrs = ["ID=Anomaly_" + str(n).zfill(width), "maxKLD=" + str(f[3]), "minPI=" + str(f[4]), "maxSI=" + str(f[5]),
+                 "minCRI=" + str(f[6]), "maxCRI=" + str(f[7])]
+        if n == 1:
+            yield "##gff-version 3\n"
+        yield "\t".join([str(f[0]), "frisk_" + version, "RIP", str(f[1]), str(f[2]), ".", "+", ".", ";".join(attrs)]) + "\n"

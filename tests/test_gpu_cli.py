@@ -1,0 +1,51 @@
+"""End-to-end CLI on the GPU: `python -m frisk_amd` semantics - score table text, caches, GFF3."""
+import json
+import os
+
+import pytest
+
+from golden_util import GOLD, INPUTS, Case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_table_caches_and_gff(tmp_path, capsys, monkeypatch):
+    from frisk_amd import postprocess as pp
+    from frisk_amd.cli import main
+    c = Case("markov_k6")
+    out = tmp_path / "T"
+    argv = ["-H", c.host, "-k", "6", "-w", "400", "-i", "150", "--RIP", "-t", str(out), "-F", "0.08", "--gffOutfile", "anom.gff3",
+            "--mergeDist", "10"]
+    assert main(argv) == 0
+    printed = capsys.readouterr().out.splitlines()
+    table = open(out / "raw_window_scores.bed").read().splitlines()
+    assert table[0] == "name\tstart\tstop\twindowKLD\tGC\tPI\tSI\tCRI"
+    assert len(table) == 1 + len(c.rows)
+    assert printed[0] == "frisk -- 0+unknown" and printed[1:] == table[1:]              # every row echoed (L1494)
+    for line, exp in zip(table[1:], c.rows):
+        f = line.split("\t")
+        assert f[:3] == [exp["name"], str(exp["start"]), str(exp["stop"])]
+        assert f[3] == pp.py2_str(exp["KLD"]) and f[4] == pp.py2_str(exp["GC"])      # 12 significant digits, as py2 prints
+        assert f[5:] == [pp.py2_str(v) for v in exp["RIP"]]
+    assert os.path.isfile(out / c.doc["genome_pickle_basename"]) and os.path.isfile(out / c.doc["window_pickle_basename"])
+    gff = open(out / "anom.gff3").read().splitlines()
+    assert gff[0] == "##gff-version 3" and all(g.split("\t")[1] == "frisk_0+unknown" for g in gff[1:])
+    n_hot = sum(1 for r in c.rows if r["KLD"] >= 0.08)
+    assert 1 <= len(gff) - 1 <= n_hot
+    # second run: both caches are reused (no recomputation), same table; py3 float text on request
+    monkeypatch.setenv("FRISK_FLOAT_REPR", "py3")
+    os.remove(out / "raw_window_scores.bed")
+    assert main(argv) == 0
+    assert not os.path.exists(out / "raw_window_scores.bed")                           # table only written when scores are computed
+    assert main(argv + ["--recalcWin", "--exitAfter", "WindowKLD"]) == 0
+    table3 = open(out / "raw_window_scores.bed").read().splitlines()
+    assert len(table3[1].split("\t")[3]) >= 16                                          # repr(), not 12 digits
+    assert abs(float(table3[1].split("\t")[3]) - c.rows[0]["KLD"]) < 1e-12
+
+
+def test_cli_zero_weight_raises_like_reference(tmp_path):
+    from frisk_amd.cli import main
+    c = Case("hq_m5k6_zero")
+    with pytest.raises(ZeroDivisionError):
+        main(["-H", c.host, "-Q", c.query, "-m", "5", "-k", "6", "-w", "500", "-i", "100", "-t", str(tmp_path / "T"),
+              "--exitAfter", "WindowKLD"])

@@ -40,7 +40,9 @@ INP = os.path.join(GOLD, "inputs")
 REF_SRC = "/root/reference/frisk/__init__.py"
 
 HOT_FUNCS = ["countN", "calcGC", "iterFasta", "crawlGenome", "prepareMaps", "rangeMaps",
-             "revComplement", "computeKmers", "IvomBuild", "KLD", "calcRIP", "makePicklePath"]
+             "revComplement", "computeKmers", "IvomBuild", "KLD", "calcRIP", "makePicklePath",
+             "FDBins", "otsu", "setKLDThresh", "natural_sort",      # row f1 (thresholds), host-side numpy
+             "mainArgs"]                                            # the argparse surface (row f2)
 
 
 def load_reference_functions():
@@ -57,8 +59,14 @@ def load_reference_functions():
     class _NP:  # calcRIP uses np.NaN (removed in numpy 2)
         NaN = float("nan")
 
-    ns = dict(Counter=Counter, math=math, copy=copy, gzip=gzip, logging=logging, pickle=pickle,
-              sys=sys, os=os, itertools=itertools, np=_NP, LETTERS=("A", "T", "G", "C"))
+    class _NPX:  # numpy, plus the alias numpy 2 removed
+        def __getattr__(self, k):
+            return float("nan") if k == "NaN" else getattr(np, k)
+
+    import re
+    ns = dict(Counter=Counter, math=math, copy=copy, gzip=gzip, logging=logging, pickle=pickle, re=re,
+              sys=sys, os=os, itertools=itertools, np=_NPX(), LETTERS=("A", "T", "G", "C"), argparse=argparse,
+              FRISK_VERSION="0+unknown")
     exec(compile(mod, "<reference hot path via lib2to3>", "exec"), ns)
     shutil.rmtree(scratch)
     return ns
@@ -196,6 +204,63 @@ def run_case(ns, name, host, query, kw, store_ivom):
     print("%-16s rows=%-4d errors=%-3d genome_meta=%s" % (name, len(out["rows"]), nerr, out["genome_meta"]))
 
 
+def run_thresholds(ns):
+    """Row f1: FDBins / otsu / setKLDThresh (L508-543, L664-690) on the KLD columns of three scan cases."""
+    class A:
+        pass
+    out = {}
+    for case in ("uniform_k4", "markov_k6", "k8_w2000", "hq_k6"):
+        doc = json.load(open(os.path.join(GOLD, case + ".json")))
+        kld = np.array([[r["KLD"]] for r in doc["rows"] if "KLD" in r], dtype=float)     # as_matrix(columns=[..]) shape (n,1)
+        logk = np.log10(kld)
+        rec = {"KLD": kld.ravel().tolist(), "FDBins": ns["FDBins"](logk)}
+        for mode, kw in (("otsu", dict(threshTypeKLD="otsu", forceThresholdKLD=None, percentileKLD=99.0)),
+                         ("pct99", dict(threshTypeKLD="percentile", forceThresholdKLD=None, percentileKLD=99.0)),
+                         ("pct80", dict(threshTypeKLD="percentile", forceThresholdKLD=None, percentileKLD=80.0)),
+                         ("force", dict(threshTypeKLD=None, forceThresholdKLD=0.05, percentileKLD=99.0))):
+            a = A()
+            a.__dict__.update(kw)
+            thr, bins = ns["setKLDThresh"](a, logk)
+            rec[mode] = [float(thr), int(bins)]
+        out[case] = rec
+    out["natural_sort"] = ns["natural_sort"](["chr10", "chr2", "Chr1", "scaffold_12b", "scaffold_3", "x"], key=str)
+    with open(os.path.join(GOLD, "thresholds.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+        fh.write("\n")
+    print("thresholds      ", {k: (v["FDBins"], v["otsu"]) for k, v in out.items() if isinstance(v, dict)})
+
+
+def run_cli_surface(ns):
+    """Row f2: every option of the reference's parser (L1130-1393): flags, dest, default, type, choices, nargs,
+    action, required.  mainArgs() parses sys.argv at its end; parse_args is intercepted to get the parser."""
+    class Grab(Exception):
+        pass
+    orig = argparse.ArgumentParser.parse_args
+
+    def grab(self, *a, **k):
+        e = Grab()
+        e.parser = self
+        raise e
+    argparse.ArgumentParser.parse_args = grab
+    try:
+        ns["mainArgs"]()
+    except Grab as e:
+        parser = e.parser
+    finally:
+        argparse.ArgumentParser.parse_args = orig
+    opts = []
+    for a in parser._actions:
+        if a.dest == "help":
+            continue
+        opts.append({"flags": list(a.option_strings), "dest": a.dest, "default": a.default,
+                     "type": getattr(a.type, "__name__", None), "choices": list(a.choices) if a.choices else None,
+                     "nargs": a.nargs, "action": type(a).__name__, "required": bool(a.required)})
+    with open(os.path.join(GOLD, "cli_surface.json"), "w") as fh:
+        json.dump({"prog": parser.prog, "options": opts}, fh, indent=0)
+        fh.write("\n")
+    print("cli_surface      %d options" % len(opts))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*")
@@ -206,6 +271,10 @@ def main():
         if opts.cases and name not in opts.cases:
             continue
         run_case(ns, name, host, query, kw, store_ivom)
+    if not opts.cases or "thresholds" in opts.cases:
+        run_thresholds(ns)
+    if not opts.cases or "cli_surface" in opts.cases:
+        run_cli_surface(ns)
 
 
 if __name__ == "__main__":
