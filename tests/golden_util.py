@@ -11,7 +11,8 @@ INPUTS = os.path.join(GOLD, "inputs")
 
 
 def case_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLD, "*.json")))
+    # scan cases have a .json (rows) and a .npz (count tables); other goldens (thresholds, cli_surface) are .json only
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLD, "*.npz")))
 
 
 class Case:
