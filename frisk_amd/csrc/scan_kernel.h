@@ -67,6 +67,7 @@ struct ScanParams {
 #define ROW_ZERO_WEIGHT 2u
 #define ROW_JUMPBACK 4u
 #define ROW_NO_MAXMER 8u
+#define ROW_BIGCOUNT 0x100u          // internal: some count above the shared level is outside the p table
 
 #pragma clang fp contract(off)
 
@@ -144,7 +145,8 @@ struct WinTables {
     uint32_t o0, o1, o2, o3;     // the first four orphan 7-mers (0xFFFFFFFF = none), wave-uniform
     int kmin;
 
-    // count of the x-mer `c` in the current window
+    // count of the x-mer `c` in the current window (PLAIN: the window has at most four orphans)
+    template <bool PLAIN = false>
     __device__ inline uint32_t count(int x, uint32_t c) const {
         if (K8) {
             if (x == 8) return t8_16[c];
@@ -153,7 +155,7 @@ struct WinTables {
                 uint32_t s = (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16);
                 // orphans: a window has one (its tail) plus one per invalid run - almost always <= 4
                 s += (c == o0 ? 1u : 0u) + (c == o1 ? 1u : 0u) + (c == o2 ? 1u : 0u) + (c == o3 ? 1u : 0u);
-                for (int o = 4; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
+                if (!PLAIN) for (int o = 4; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
                 return s;
             }
         }
@@ -460,11 +462,15 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             // ---- stage 2: marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] --------------
             auto marg_level = [&](int x, int first, int step) {
                 const uint32_t ox = uint32_t(table_offset(kmin, x)), ou = uint32_t(table_offset(kmin, x + 1));
+                bool big = false;
                 for (uint32_t c = first; c < (1u << (2 * x)); c += step) {
                     const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ou + 4 * c);     // 8-byte aligned
-                    small16[ox + c] = uint16_t(small16[ox + c] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) +
-                                               (ch.y >> 16));
+                    const uint32_t c0 = ch.x & 0xFFFFu, c1 = ch.x >> 16, c2 = ch.y & 0xFFFFu, c3 = ch.y >> 16;
+                    small16[ox + c] = uint16_t(small16[ox + c] + c0 + c1 + c2 + c3);
+                    big |= (c0 | c1 | c2 | c3) >= FRISK_PTAB;       // some count of order x+1 is outside the p table
                 }
+                // counts only shrink with the order, so "no big count at order lv+1" covers every order above lv
+                if (x == lv && big) atomicOr(&misc[M_FLAGS], ROW_BIGCOUNT);
             };
             {
                 int x = ks - 1;
@@ -557,7 +563,10 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             // ---- stage 4: IVOM of every max-mer position, window side (L394-450) and genome side (table) ----
             // Evaluated for EVERY position of the lane (straight-line code: independent division chains of
             // different positions interleave); only representatives are accumulated.
-            auto window_ivom = [&](uint32_t code) -> double {
+            // plain_c: std::true_type when every count above lv fits the p table and the window has <= 4 orphans
+            // (nearly always) - then the recursion is branch-free
+            auto window_ivom = [&](uint32_t code, auto plain_c) -> double {
+                constexpr bool PLAIN = decltype(plain_c)::value;
                 wsum_t W = 0;
                 double I = 0.0;
                 if (lv) {
@@ -567,8 +576,9 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                     I = pre_i[pc];
 #pragma unroll
                     for (int x = LV + 1; x <= kmax; ++x) {
-                        const uint32_t cx = T.count(x, code >> (2 * (kmax - x)));
-                        const double p = (cx < FRISK_PTAB) ? ptab[(x - LV - 1) * FRISK_PTAB + cx] : prob(x, cx);
+                        const uint32_t cx = T.template count<PLAIN>(x, code >> (2 * (kmax - x)));
+                        const double p = (PLAIN || cx < FRISK_PTAB) ? ptab[(x - LV - 1) * FRISK_PTAB + (PLAIN ? (cx & (FRISK_PTAB - 1)) : cx)]
+                                                                    : prob(x, cx);
                         ivom_step(x, cx, W, I, p);
                     }
                 } else {
@@ -579,23 +589,27 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 }
                 return I;
             };
+            const bool plain = lv && !(misc[M_FLAGS] & ROW_BIGCOUNT) && n_orph <= 4;
             double iw_keep[NREG], ig_keep[NREG];
             Fix128 accw = 0, accg = 0;
             bool zero_w = false;
+            auto stage4 = [&](auto plain_c) {
 #pragma unroll
-            for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
-                if (ITS > 0 && it * NT >= n) { iw_keep[it] = 0.0; ig_keep[it] = 0.0; continue; }   // wave-uniform
-                const bool rep = (repmask >> it) & 1ull;
-                if (ITS == 0 && !rep) continue;
-                const uint32_t code = code16_at(it) >> kshift;
-                const double Ig = P.ig[code];                   // unconditional gather (code < 4^K always)
-                const double Iw = window_ivom(code);
-                zero_w |= rep && (Ig != Ig);
-                const double iw = rep ? Iw : 0.0, ig = (rep && Ig == Ig) ? Ig : 0.0;
-                if (ITS > 0) { iw_keep[it] = iw; ig_keep[it] = rep ? Ig : 0.0; }
-                accw += to_fix(iw);
-                accg += to_fix(ig);
-            }
+                for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
+                    if (ITS > 0 && it * NT >= n) { iw_keep[it] = 0.0; ig_keep[it] = 0.0; continue; }   // wave-uniform
+                    const bool rep = (repmask >> it) & 1ull;
+                    if (ITS == 0 && !rep) continue;
+                    const uint32_t code = code16_at(it) >> kshift;
+                    const double Ig = P.ig[code];                   // unconditional gather (code < 4^K always)
+                    const double Iw = window_ivom(code, plain_c);
+                    zero_w |= rep && (Ig != Ig);
+                    const double iw = rep ? Iw : 0.0, ig = (rep && Ig == Ig) ? Ig : 0.0;
+                    if (ITS > 0) { iw_keep[it] = iw; ig_keep[it] = rep ? Ig : 0.0; }
+                    accw += to_fix(iw);
+                    accg += to_fix(ig);
+                }
+            };
+            if (plain) stage4(std::true_type{}); else stage4(std::false_type{});
             if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
             block_sum2<NW>(accw, accg, scratch_base, tid);          // sumWindowIVOM of both sides (L450)
             const double Sw = fix_to_double(accw), Sg = fix_to_double(accg);
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 if (ITS == 0 && !rep) continue;
                 double Iw, Ig;
                 if (ITS > 0) { Iw = iw_keep[it]; Ig = ig_keep[it]; }
-                else { const uint32_t code = code16_at(it) >> kshift; Iw = window_ivom(code); Ig = P.ig[code]; }
+                else { const uint32_t code = code16_at(it) >> kshift; Iw = window_ivom(code, std::false_type{}); Ig = P.ig[code]; }
                 const double pw = div_exact(Iw, Sw);                        // L453-454
                 const double pg = div_exact(Ig, Sg);
                 const double t = pw * div_exact(log_pos(div_exact(pw, pg)), LN2);   // L470

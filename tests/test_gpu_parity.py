@@ -99,6 +99,33 @@ def test_scan_matches_numpy_oracle(kmin, kmax, w, inc, mask_host, rip):
         assert checked > 0
 
 
+def test_many_orphans_and_big_counts():
+    """The scan kernel's slow paths: > 4 orphan 7-mers per window (many invalid runs) and counts outside the
+    p table (low-complexity sequence), against the numpy oracle."""
+    from frisk_amd import synth
+    base = bytearray(synth.scaffold(30000, 21, 0, island_frac=0.3))
+    for pos in range(40, 30000, 53):            # an N every 53 bases: ~95 orphans per 5 kb window, < 30 % N
+        base[pos] = ord("N")
+    low = bytearray(synth.scaffold(24000, 22, 0))
+    low[3000:9000] = b"A" * 6000                # poly-A and a dinucleotide repeat: counts of thousands
+    low[12000:16000] = b"AC" * 2000
+    low[7000] = ord("n")
+    seqs = [bytes(base), bytes(low)]
+    for kmin, kmax, w, inc in ((1, 8, 5000, 1000), (1, 8, 2000, 500), (1, 7, 3000, 1000)):
+        (sym, meta), rows = oracle_rows(seqs, kmin, kmax, w, inc)
+        with make_engine(kmin, kmax) as e:
+            e.load(seqs)
+            e.profile_reset(); e.profile_add(); e.profile_finalize()
+            res = e.scan(w, inc, debug=True)
+            kept = np.nonzero(res.kept)[0]
+            assert len(kept) == len(rows) > 10
+            for r, exp in zip(kept.tolist(), rows):
+                assert np.array_equal(res.counts[r].astype(np.int64), exp["counts"])
+                assert abs(float(res.kld[r]) - exp["KLD"]) <= KLD_TOL
+            fast = e.scan(w, inc)
+            assert np.array_equal(fast.kld, res.kld, equal_nan=True)        # non-debug build: same bits
+
+
 def test_profile_is_linear_over_ranges_and_batches():
     lens = [50000, 20011, 999]
     seqs = synth_seqs(lens, 11, island_frac=0.1, n_frac=0.1, lower_frac=0.1)
