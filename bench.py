@@ -133,6 +133,12 @@ def main():
         # algorithmic bytes of one scan launch: 2-bit bases once, 40 B per emitted row, genome table once
         b_alg = 0.25 * total_bases + 40.0 * rows + 8.0 * sum(4 ** x for x in range(KMIN, KMAX + 1))
         achieved = b_alg / (scan_avg * 1e-3) / 1e9
+        traffic = None      # HBM bytes per scan launch from PMC counters (collected offline with rocprofv3, same workload)
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload_bases_per_gpu") == total_bases and tj.get("candidate_windows_per_gpu") == n_cand:
+                traffic = tj["hbm_bytes_per_launch"]
         out = {
             "metric": "windows/sec (k=1..8, w=5kb, s=1kb)", "value": rows_all / (elapsed / opts.steps),
             "unit": "windows/s", "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
@@ -147,7 +153,7 @@ def main():
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
             "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "scan_kernel", "algorithmic_bytes_per_launch": b_alg,
                          "note": "the path is not HBM-limited at any plausible rate (290 B/window); the binding "
                                  "limits are LDS atomics and FP64 divide/log issue - see DESIGN.md"},

@@ -151,12 +151,13 @@ class Engine:
         assert raw.shape == (self.nprof + 4,)
         self._check(self._lib.frisk_profile_import_host(self._ctx, _ptr(raw)))
 
-    def profile_allreduce(self, group=None):
+    def profile_allreduce(self, group=None, force=False):
         """Sum the raw (linear) profile over all ranks: ONE all-reduce (RCCL when the process group's
-        backend is nccl; gloo works too for the CPU rehearsal of the multi-rank path)."""
+        backend is nccl; gloo works too for the CPU rehearsal of the multi-rank path).  force=True runs the
+        collective even in a one-rank group (tests)."""
         import torch
         import torch.distributed as dist
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
             return
         n = self.nprof + 4
         if dist.get_backend(group) == "nccl":

@@ -256,3 +256,25 @@ def test_full_size_properties(shape):
             assert np.array_equal(res.start[reg], 1 + inc * np.arange(len(reg)))
         # islands exist: the score distribution has a tail
         assert res.kld[k].max() > 1.3 * np.median(res.kld[k])
+
+
+def test_rccl_allreduce_path_single_rank():
+    """The nccl(=RCCL) branch of Engine.profile_allreduce: export to a torch tensor, all_reduce(int64, sum),
+    import - exercised in a one-rank process group (the 8-GPU run is the driver's)."""
+    import torch.distributed as dist
+    seqs = synth_seqs([40000, 7000], 13, n_frac=0.05)
+    with make_engine(1, 8) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add()
+        before = e.profile_raw()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1)
+        try:
+            e.profile_allreduce(force=True)
+        finally:
+            dist.destroy_process_group()
+        assert np.array_equal(e.profile_raw(), before)
+        e.profile_finalize()
+        from oracle import frisk_oracle_np as N
+        sym, tl, ex, nn = e.profile_get()
+        osym, ometa = N.genome_profile(seqs, 1, 8)
+        assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
