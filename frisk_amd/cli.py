@@ -5,8 +5,9 @@ choices, the inverted store_false semantics of --recalc/--recalcWin), same files
 caches, GFF3) and the same row echo on stdout.  Phase A and phase B run through libfrisk_hip.so
 (frisk_amd.hotpath); thresholds, merging and GFF3 writing are host numpy (frisk_amd.postprocess).
 
-Out of scope here: --hmmKLD (needs hmmlearn, row f3), --runProjection/--cluster
-(sklearn analysis on a few hundred rows), --graphics (seaborn/matplotlib), --gffIn intersections (bedtools).
+--hmmKLD runs frisk_amd.hmm (own 2-state Gaussian HMM; hmmlearn is absent and seeds randomly - parity unpinned).
+Out of scope here: --runProjection/--cluster (sklearn analysis on a few hundred rows),
+--graphics (seaborn/matplotlib), --gffIn intersections (bedtools).
 Those options are accepted, as in the reference, and reported as unavailable if used.
 
 Run under `python -m torch.distributed.run --nproc-per-node N -m frisk_amd ...` to shard one job over N GPUs
@@ -148,7 +149,7 @@ def main(argv=None):
     querySeq = args.querySeq or args.hostSeq
     if rank == 0 and not os.path.isdir(os.path.abspath(args.tempDir)):
         os.makedirs(os.path.abspath(args.tempDir))
-    for opt, why in (("hmmKLD", "needs hmmlearn (row f3)"), ("runProjection", "sklearn projection is out of scope"),
+    for opt, why in (("runProjection", "sklearn projection is out of scope"),
                      ("graphics", "plotting is out of scope"), ("gffIn", "bedtools intersections are out of scope")):
         if getattr(args, opt):
             log.warning("--%s is not available in this build: %s", opt, why)
@@ -210,6 +211,12 @@ def main(argv=None):
     threshold, _bins = pp.setKLDThresh(args, logKLD)
     threshold = float(np.ravel(threshold)[0])
     log.info("log10(KLD) threshold = %s", threshold)
+    if args.hmmKLD:                                                     # L1537-1548
+        from .hmm import hmm2BED, hmmBED2GFF
+        intervals, _model = hmm2BED(rows)
+        with open(os.path.join(args.tempDir, args.hmmOutfile), "w") as fh:
+            for line in hmmBED2GFF(intervals):
+                fh.write(line)
     anomalies, _sel = pp.thresholdKLD(rows, threshold, args, merge=True)
     log.info("Detected %s features above KLD threshold.", len(anomalies))
     if args.gffOutfile:

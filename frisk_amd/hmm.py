@@ -1,0 +1,151 @@
+"""2-state Gaussian HMM segmentation of the KLD track - host numpy.
+
+The reference fits `hmmlearn.hmm.GaussianHMM(n_components=2, covariance_type="full")` on all non-NaN window scores
+stacked as ONE sequence (frisk/__init__.py L1537-1541) and Viterbi-decodes each scaffold (hmm2BED L757-785),
+then writes runs of equal state as GFF3 features (range2interval L787-795, hmmBED2GFF L589-596).
+hmmlearn is a third-party dependency that is absent here and seeds its k-means initialisation randomly, so
+parity for the fitted numbers is UNPINNED: this module restates the documented model (Baum-Welch with hmmlearn's
+default priors: covars_prior 1e-2, covars_weight 1, n_iter 10, tol 1e-2; Viterbi decoding) with a deterministic
+initialisation (1-D 2-means started at the extremes; state 0 = the lower mean).  What is pinned by tests is the
+reference's own logic around the model: stacking, per-scaffold decoding, run extraction, the string sort of
+the intervals, and the GFF3 text.
+"""
+import numpy as np
+
+from .postprocess import FRISK_VERSION
+
+_LOG2PI = np.log(2.0 * np.pi)
+
+
+def _logsumexp(a, axis):
+    m = np.max(a, axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0)
+    return np.squeeze(m, axis=axis) + np.log(np.sum(np.exp(a - m), axis=axis))
+
+
+class GaussianHMM2:
+    """1-D, 2 states, one variance per state ("full" covariance of one feature)."""
+
+    def __init__(self, n_iter=10, tol=1e-2, min_covar=1e-3, covars_prior=1e-2):
+        self.n_iter, self.tol, self.min_covar, self.covars_prior = n_iter, tol, min_covar, covars_prior
+
+    # -- initialisation: 2-means from the extremes, hmmlearn-style shared variance, flat start / transitions
+    def _init(self, x):
+        c = np.array([x.min(), x.max()], dtype=float)
+        for _ in range(100):
+            lab = np.abs(x[:, None] - c[None, :]).argmin(axis=1)
+            new = np.array([x[lab == s].mean() if np.any(lab == s) else c[s] for s in (0, 1)])
+            if np.allclose(new, c):
+                break
+            c = new
+        self.means_ = np.sort(c)
+        self.covars_ = np.full(2, np.var(x) + self.min_covar)
+        self.startprob_ = np.array([0.5, 0.5])
+        self.transmat_ = np.full((2, 2), 0.5)
+
+    def _loglik(self, x):
+        return -0.5 * (_LOG2PI + np.log(self.covars_)[None, :] + (x[:, None] - self.means_[None, :]) ** 2 / self.covars_[None, :])
+
+    def _forward_backward(self, b):
+        n = b.shape[0]
+        with np.errstate(divide="ignore"):
+            lt, ls = np.log(self.transmat_), np.log(self.startprob_)
+        fwd = np.empty((n, 2))
+        fwd[0] = ls + b[0]
+        for t in range(1, n):
+            fwd[t] = _logsumexp(fwd[t - 1][:, None] + lt, axis=0) + b[t]
+        bwd = np.zeros((n, 2))
+        for t in range(n - 2, -1, -1):
+            bwd[t] = _logsumexp(lt + (b[t + 1] + bwd[t + 1])[None, :], axis=1)
+        return fwd, bwd, _logsumexp(fwd[-1], axis=0), lt
+
+    def fit(self, x):
+        x = np.asarray(x, dtype=float).ravel()
+        self._init(x)
+        prev = -np.inf
+        for _ in range(self.n_iter):
+            b = self._loglik(x)
+            fwd, bwd, ll, lt = self._forward_backward(b)
+            post = np.exp(fwd + bwd - ll)
+            post /= post.sum(axis=1, keepdims=True)
+            if len(x) > 1:
+                xi = fwd[:-1, :, None] + lt[None] + (b[1:] + bwd[1:])[:, None, :] - ll
+                trans = np.exp(_logsumexp(xi, axis=0))
+            else:
+                trans = np.zeros((2, 2))
+            # M step (hmmlearn's defaults: flat Dirichlet priors, means_weight 0, covars_prior/weight 1e-2 / 1)
+            self.startprob_ = post[0] / post[0].sum()
+            rows = trans.sum(axis=1, keepdims=True)
+            self.transmat_ = np.where(rows > 0, trans / np.where(rows > 0, rows, 1.0), 0.5)
+            w = post.sum(axis=0)
+            self.means_ = (post * x[:, None]).sum(axis=0) / w
+            self.covars_ = (self.covars_prior + (post * (x[:, None] - self.means_[None, :]) ** 2).sum(axis=0)) / w
+            self.covars_ = np.maximum(self.covars_, self.min_covar)
+            if ll - prev < self.tol:
+                break
+            prev = ll
+        return self
+
+    def predict(self, x):
+        """Viterbi path."""
+        x = np.asarray(x, dtype=float).ravel()
+        if x.size == 0:
+            return np.zeros(0, dtype=int)
+        b = self._loglik(x)
+        with np.errstate(divide="ignore"):
+            lt, ls = np.log(self.transmat_), np.log(self.startprob_)
+        n = x.size
+        score = ls + b[0]
+        back = np.zeros((n, 2), dtype=int)
+        for t in range(1, n):
+            cand = score[:, None] + lt
+            back[t] = cand.argmax(axis=0)
+            score = cand.max(axis=0) + b[t]
+        path = np.empty(n, dtype=int)
+        path[-1] = int(score.argmax())
+        for t in range(n - 1, 0, -1):
+            path[t - 1] = back[t, path[t]]
+        return path
+
+
+def state_runs(states, value):
+    """(first, last) index of every maximal run of `value` (findBaseRanges L91-104 with minlen 0: single
+    windows are runs too)."""
+    runs, start = [], None
+    for i, s in enumerate(list(states) + [None]):
+        if s == value and start is None:
+            start = i
+        elif s != value and start is not None:
+            runs.append((start, i - 1))
+            start = None
+    return runs
+
+
+def hmm2BED(rows, model=None):
+    """rows: (name, start, stop, KLD, ...) in table order.  Fits the model on all non-NaN scores stacked
+    (L1541), decodes per scaffold, and returns intervals (name, start, stop, 'State1'|'State2') as STRINGS
+    sorted the way the reference sorts them - lexicographically on the string fields (L783)."""
+    good = [r for r in rows if not (isinstance(r[3], float) and r[3] != r[3])]
+    if model is None:
+        model = GaussianHMM2().fit(np.array([float(r[3]) for r in good]))
+    names = []
+    for r in good:
+        if r[0] not in names:
+            names.append(r[0])
+    out = []
+    for name in names:
+        win = [r for r in good if r[0] == name]
+        states = model.predict(np.array([float(r[3]) for r in win]))
+        for value, label in ((0, "State1"), (1, "State2")):
+            for a, b in state_runs(states.tolist(), value):
+                out.append((str(name), str(int(win[a][1])), str(int(win[b][2])), label))
+    return sorted(out, key=lambda t: (t[0], t[1], t[2])), model
+
+
+def hmmBED2GFF(intervals, version=FRISK_VERSION):
+    width = len(str(len(intervals)))
+    for n, rec in enumerate(intervals, 1):
+        if n == 1:
+            yield "##gff-version 3\n"
+        yield "\t".join([rec[0], "frisk_" + version, str(rec[3]), str(rec[1]), str(rec[2]), ".", "+", ".",
+                         "ID=" + rec[3] + "_" + str(n).zfill(width)]) + "\n"
