@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(const int64_t* __restri
 // L411-450).  It depends only on the genome profile, so it is computed once per profile; the scan
 // kernel gathers from it and renormalises over the window's present max-mers (L453-454).
 // A zero running weight or a zero divisor is a ZeroDivisionError in the reference (L437, L416-424):
-// encoded as NaN and reported per window if such a max-mer is present there.
+// encoded as NaN and reported per window if such a max-mer is present there.  The genome side keeps the
+// reference's operation order (it is computed once; the scan kernel uses the closed form on the window side).
 // ------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void genome_ivom_kernel(const int64_t* __restrict__ sym, int kmin, int kmax,

@@ -17,16 +17,20 @@
 // The update of the max-mer table is a returning atomic; the lane that sees the old value 0 becomes the
 // *representative* of that max-mer and later evaluates its IVOM recursion, so no scan over the 4^K bins is
 // ever needed, and bins are re-zeroed by their representatives instead of a 128 KiB clear.
-// The IVOM value after order x depends only on the x-mer prefix, so the first five recursion steps are
-// evaluated once per present 5-mer (<= 1024 per window) into an LDS table and every representative continues
-// from there: 3 instead of 8 division-heavy steps per max-mer at K = 8, with bit-identical results.
+// Scoring uses two algebraic identities of the reference's arithmetic (IvomBuild L426-446, KLD L465-470):
+//   * the interpolation recursion  I_x = a_x p_x + (1-a_x) I_{x-1},  a_x = w_x / (w_m+..+w_x),  telescopes
+//     (1 - a_x = W_{x-1}/W_x) to the closed form  I_K = (sum_x w_x p_x) / W_K = (sum_x c_x^2 4^x / D_x) / (sum_x c_x 4^x):
+//     one division per max-mer instead of two per order.  The partial sums over orders kmin..5 depend only on
+//     the 5-mer prefix and are computed once per present 5-mer (<= 1024 per window) into an LDS table;
+//   * with Pw = Iw/Sw and Pg = Ig/Sg,  sum Pw log(Pw/Pg) = T/Sw - log Sw + log Sg,  T = sum Iw log(Iw/Ig):
+//     one pass over the max-mers, no normalisation pass.
+// Same mathematics, different rounding: |KLD - reference| stays below ~1e-13 (north-star bound 1e-6; the parity
+// tests assert 1e-11 / 1e-10).  The oracles keep the reference's operation order.
 // With only 4 wavefronts per SIMD (the 128 KiB table allows one workgroup per CU) latency has to be hidden
 // inside each wavefront: the per-position loops are fully unrolled (ITS iterations, a template parameter),
-// loads and table gathers are unconditional and issued ahead of their use, and the recursion is evaluated
-// for every lane (non-representatives are masked out when accumulating) so that the compiler can interleave
-// the independent division chains of different positions.
-// FP64 throughout (the KLD sum cancels from O(1) terms to O(1e-2)); contraction off so that every
-// product/sum rounds exactly as CPython's does.  No MFMA: this is histogramming + a scalar recurrence.
+// loads and table gathers are unconditional and issued ahead of their use, and every position of a lane is
+// evaluated in straight-line code (non-representatives are masked out when accumulating).
+// FP64 throughout (the terms cancel from O(1) to O(1e-2)).  No MFMA: this is histogramming + scalar arithmetic.
 #pragma once
 #include <type_traits>
 
@@ -67,7 +71,6 @@ struct ScanParams {
 #define ROW_ZERO_WEIGHT 2u
 #define ROW_JUMPBACK 4u
 #define ROW_NO_MAXMER 8u
-#define ROW_BIGCOUNT 0x100u          // internal: some count above the shared level is outside the p table
 
 #pragma clang fp contract(off)
 
@@ -93,9 +96,9 @@ struct LdsLayout {
     uint32_t small;     // byte offset of the small tables (orders kmin..ks), u16 bins
     uint32_t small_bytes;
     uint32_t orphans;   // u16 list
-    uint32_t pre_i;     // f64[4^lv]: IVOM value after order lv, per lv-mer prefix
+    uint32_t pre_i;     // f64[4^lv]: sum_{x<=lv} c_x^2 4^x/D_x of the lv-mer prefix
     uint32_t pre_w;     // u32[4^lv]: running weight sum after order lv
-    uint32_t ptab;      // f64[3][FRISK_PTAB]: c / ((S-(x-1))*2) for small counts c, orders above lv
+    uint32_t rtab;      // f64[16]: 4^x / ((S-(x-1))*2) per order x (window constants)
     uint32_t misc;      // 2 x 16 u32 counters (double-buffered by window parity) + reduction scratch
     uint32_t total;
 };
@@ -103,9 +106,8 @@ struct LdsLayout {
 // order at which the recursion is shared between max-mers (0 = not shared)
 __host__ __device__ inline int shared_level(int kmin, int kmax) { return (kmin <= 5 && kmax >= 6) ? 5 : 0; }
 
-#define FRISK_PTAB 64
 #define FRISK_MISC_SLOTS 16
-#define FRISK_MISC_BYTES (2 * FRISK_MISC_SLOTS * 4 + 2 * 16 * 4 * 8)   // counters x2, scratch x2 (16 waves x 2 x 128 bit)
+#define FRISK_MISC_BYTES (2 * FRISK_MISC_SLOTS * 4 + 16 * 6 * 8)       // counters x2, scratch (16 waves x 3 x 128 bit)
 
 __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap) {
     LdsLayout L;
@@ -125,8 +127,8 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
     if (lv) o += (1u << (2 * lv)) * 8;
     L.pre_w = o;
     if (lv) o += (1u << (2 * lv)) * 4;
-    L.ptab = o;
-    if (lv) o += 3 * FRISK_PTAB * 8;
+    L.rtab = o;
+    o += 16 * 8;
     L.misc = o;
     o += FRISK_MISC_BYTES;
     L.total = (o + 15) / 16 * 16;
@@ -212,9 +214,13 @@ __device__ inline Fix128 to_fix(double m) {
 }
 
 __device__ inline double fix_to_double(Fix128 a) {
-    const uint32_t l3 = uint32_t(a), l2 = uint32_t(a >> 32), l1 = uint32_t(a >> 64);
-    const int32_t hi = int32_t(a >> 96);
-    return ((double(l3) * 0x1p-84 + double(l2) * 0x1p-52) + double(l1) * 0x1p-20) + double(hi) * 0x1p12;
+    // sign-magnitude: converting the two's-complement limbs of a negative sum directly would add small limbs to
+    // ~2^12 before the top limb cancels it, losing everything below 2^-41
+    const bool neg = a < 0;
+    const unsigned __int128 m = neg ? (unsigned __int128)(-a) : (unsigned __int128)a;
+    const uint32_t l3 = uint32_t(m), l2 = uint32_t(m >> 32), l1 = uint32_t(m >> 64), l0 = uint32_t(m >> 96);
+    const double v = ((double(l3) * 0x1p-84 + double(l2) * 0x1p-52) + double(l1) * 0x1p-20) + double(l0) * 0x1p12;
+    return neg ? -v : v;
 }
 
 __device__ inline Fix128 fix_shfl_down(Fix128 a, int o) {
@@ -238,27 +244,31 @@ __device__ inline double div_exact(double n, double d) {
     return __builtin_fma(e, r, q);
 }
 
-// sum two accumulators over the workgroup; every thread returns the same totals.  One barrier: the caller
-// alternates between two scratch areas, and a scratch area is rewritten only several barriers later.
+// sum three accumulators over the workgroup; every thread returns the same totals.  One barrier: the scratch is
+// rewritten only after the window's last barrier.
 template <int NW>
-__device__ inline void block_sum2(Fix128& a, Fix128& b, uint64_t* scratch, int tid) {
+__device__ inline void block_sum3(Fix128& a, Fix128& b, Fix128& c, uint64_t* scratch, int tid) {
     for (int o = 32; o > 0; o >>= 1) {
         a += fix_shfl_down(a, o);
         b += fix_shfl_down(b, o);
+        c += fix_shfl_down(c, o);
     }
     if ((tid & 63) == 0) {
-        uint64_t* p = scratch + (tid >> 6) * 4;
+        uint64_t* p = scratch + (tid >> 6) * 6;
         p[0] = uint64_t(a); p[1] = uint64_t(a >> 64); p[2] = uint64_t(b); p[3] = uint64_t(b >> 64);
+        p[4] = uint64_t(c); p[5] = uint64_t(c >> 64);
     }
     __syncthreads();
-    Fix128 sa = 0, sb = 0;
+    Fix128 sa = 0, sb = 0, sc = 0;
     for (int w = 0; w < NW; ++w) {
-        const uint64_t* p = scratch + w * 4;
+        const uint64_t* p = scratch + w * 6;
         sa += Fix128((unsigned __int128)p[0] | ((unsigned __int128)p[1] << 64));
         sb += Fix128((unsigned __int128)p[2] | ((unsigned __int128)p[3] << 64));
+        sc += Fix128((unsigned __int128)p[4] | ((unsigned __int128)p[5] << 64));
     }
     a = sa;
     b = sb;
+    c = sc;
 }
 
 // ITS > 0: the window has at most ITS*NT positions; per-position loops are fully unrolled and the per-position
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
     uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L.orphans);
     double* pre_i = reinterpret_cast<double*>(lds + L.pre_i);
     uint32_t* pre_w = reinterpret_cast<uint32_t*>(lds + L.pre_w);
-    double* ptab = reinterpret_cast<double*>(lds + L.ptab);
+    double* rtab = reinterpret_cast<double*>(lds + L.rtab);
     using wsum_t = typename std::conditional<(ITS > 0), uint32_t, unsigned long long>::type;   // W < 2^32 for n <= 8192
     uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L.misc);
     uint64_t* scratch_base = reinterpret_cast<uint64_t*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
@@ -462,15 +472,11 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             // ---- stage 2: marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] --------------
             auto marg_level = [&](int x, int first, int step) {
                 const uint32_t ox = uint32_t(table_offset(kmin, x)), ou = uint32_t(table_offset(kmin, x + 1));
-                bool big = false;
                 for (uint32_t c = first; c < (1u << (2 * x)); c += step) {
                     const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ou + 4 * c);     // 8-byte aligned
-                    const uint32_t c0 = ch.x & 0xFFFFu, c1 = ch.x >> 16, c2 = ch.y & 0xFFFFu, c3 = ch.y >> 16;
-                    small16[ox + c] = uint16_t(small16[ox + c] + c0 + c1 + c2 + c3);
-                    big |= (c0 | c1 | c2 | c3) >= FRISK_PTAB;       // some count of order x+1 is outside the p table
+                    small16[ox + c] = uint16_t(small16[ox + c] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) +
+                                               (ch.y >> 16));
                 }
-                // counts only shrink with the order, so "no big count at order lv+1" covers every order above lv
-                if (x == lv && big) atomicOr(&misc[M_FLAGS], ROW_BIGCOUNT);
             };
             {
                 int x = ks - 1;
@@ -504,38 +510,30 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
             }
             T.kmin = kmin;
 
-            // one recursion step (L399-446).  The first step needs no special case: W == wt gives a == 1.0 and
-            // 1.0*p + 0.0*0.0 == p exactly.
-            auto ivom_step = [&](int x, uint32_t cx, wsum_t& W, double& I, double p) {
-                const wsum_t wt = wsum_t(cx) << (2 * x);                            // count * 4**x (L399-408)
-                W += wt;
-                const double a = div_exact(double(wt), double(W));                  // L437
-                I = a * p + ((1.0 - a) * I);                                        // L442-446
-            };
-            auto prob = [&](int x, uint32_t cx) -> double {                         // L401-409
-                return div_exact(double(cx), double(int32_t((S - (x - 1)) * 2)));
-            };
-
-            // ---- stage 3: shared prefix - IVOM after order lv for every present lv-mer ----------------------
+            // ---- stage 3: window constants r_x = 4^x / D_x, D_x = (S-(x-1))*2 (L401-409), and the shared prefix ---
+            if (tid >= 32 && tid < 32 + 9) {
+                const int x = tid - 32;                                     // orders 0..8 (0 unused)
+                rtab[x] = double(1u << (2 * x)) / double(int32_t((S - (x - 1)) * 2));
+            }
+            if (lv) __syncthreads();
+            // numerator / denominator of the closed form, orders kmin..lv, for every present lv-mer
             if (lv) {
                 for (uint32_t c = tid; c < (1u << (2 * lv)); c += NT) {
                     if (T.count(lv, c) == 0) continue;
                     wsum_t W = 0;
-                    double I = 0.0;
+                    double A = 0.0;
                     for (int x = kmin; x <= lv; ++x) {
                         const uint32_t cx = T.count(x, c >> (2 * (lv - x)));
-                        ivom_step(x, cx, W, I, prob(x, cx));
+                        const double cd = double(cx);
+                        W += wsum_t(cx) << (2 * x);                         // count * 4**x (L399-408)
+                        A = __builtin_fma(cd * cd, rtab[x], A);             // w_x * p_x = c^2 4^x / D_x
                     }
-                    pre_i[c] = I;
+                    pre_i[c] = A;
                     pre_w[c] = uint32_t(W);         // < 65536 * 4^6
                 }
-                // p = c / ((S-(x-1))*2) depends only on (x, c): tabulate it for the small counts that dominate
-                // the orders above lv (one division per entry instead of one per max-mer and order)
-                for (int e = tid; e < (kmax - lv) * FRISK_PTAB; e += NT)
-                    ptab[e] = prob(lv + 1 + e / FRISK_PTAB, uint32_t(e % FRISK_PTAB));
-                __syncthreads();
             }
-            STOP_AFTER(3, lv ? pre_i[tid & 1023] : 0.0)
+            __syncthreads();
+            STOP_AFTER(3, lv ? pre_i[tid & 1023] : rtab[1])
 
             if (DEBUG && P.dbg_counts) {
                 uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
@@ -560,85 +558,68 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                 cri = (pi == 0.0 || si == 0.0) ? qnan : pi - si;        // "if PI and SI" (L491): 0.0 is falsy
             }
 
-            // ---- stage 4: IVOM of every max-mer position, window side (L394-450) and genome side (table) ----
-            // Evaluated for EVERY position of the lane (straight-line code: independent division chains of
-            // different positions interleave); only representatives are accumulated.
-            // plain_c: std::true_type when every count above lv fits the p table and the window has <= 4 orphans
-            // (nearly always) - then the recursion is branch-free
+            // ---- stage 4: every max-mer position of the lane: window-side IVOM (closed form), genome side from the
+            // table, and the three sums  Sw = sum Iw,  Sg = sum Ig,  T = sum Iw ln(Iw/Ig)  over representatives
             auto window_ivom = [&](uint32_t code, auto plain_c) -> double {
-                constexpr bool PLAIN = decltype(plain_c)::value;
+                constexpr bool PLAIN = decltype(plain_c)::value;            // <= 4 orphans: no list loop in count(7)
                 wsum_t W = 0;
-                double I = 0.0;
+                double A = 0.0;
                 if (lv) {
                     constexpr int LV = 5;                                   // == shared_level() whenever it is not 0
                     const uint32_t pc = code >> (2 * (kmax - LV));
                     W = pre_w[pc];
-                    I = pre_i[pc];
+                    A = pre_i[pc];
 #pragma unroll
                     for (int x = LV + 1; x <= kmax; ++x) {
                         const uint32_t cx = T.template count<PLAIN>(x, code >> (2 * (kmax - x)));
-                        const double p = (PLAIN || cx < FRISK_PTAB) ? ptab[(x - LV - 1) * FRISK_PTAB + (PLAIN ? (cx & (FRISK_PTAB - 1)) : cx)]
-                                                                    : prob(x, cx);
-                        ivom_step(x, cx, W, I, p);
+                        const double cd = double(cx);
+                        W += wsum_t(cx) << (2 * x);
+                        A = __builtin_fma(cd * cd, rtab[x], A);
                     }
                 } else {
                     for (int x = kmin; x <= kmax; ++x) {
                         const uint32_t cx = T.count(x, code >> (2 * (kmax - x)));
-                        ivom_step(x, cx, W, I, prob(x, cx));
+                        const double cd = double(cx);
+                        W += wsum_t(cx) << (2 * x);
+                        A = __builtin_fma(cd * cd, rtab[x], A);
                     }
                 }
-                return I;
+                return div_exact(A, double(W));
             };
-            const bool plain = lv && !(misc[M_FLAGS] & ROW_BIGCOUNT) && n_orph <= 4;
-            double iw_keep[NREG], ig_keep[NREG];
-            Fix128 accw = 0, accg = 0;
+            Fix128 accw = 0, accg = 0, acct = 0;
             bool zero_w = false;
             auto stage4 = [&](auto plain_c) {
 #pragma unroll
                 for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
-                    if (ITS > 0 && it * NT >= n) { iw_keep[it] = 0.0; ig_keep[it] = 0.0; continue; }   // wave-uniform
+                    // (iterations past the window are not skipped: their lanes are clamped and masked, and a
+                    //  branch here would split the unrolled body into blocks the scheduler cannot interleave)
                     const bool rep = (repmask >> it) & 1ull;
                     if (ITS == 0 && !rep) continue;
                     const uint32_t code = code16_at(it) >> kshift;
-                    const double Ig = P.ig[code];                   // unconditional gather (code < 4^K always)
+                    const double Ig = P.ig[code];                           // unconditional gather (code < 4^K always)
                     const double Iw = window_ivom(code, plain_c);
-                    zero_w |= rep && (Ig != Ig);
-                    const double iw = rep ? Iw : 0.0, ig = (rep && Ig == Ig) ? Ig : 0.0;
-                    if (ITS > 0) { iw_keep[it] = iw; ig_keep[it] = rep ? Ig : 0.0; }
-                    accw += to_fix(iw);
-                    accg += to_fix(ig);
+                    const bool bad = (Ig != Ig);                            // zero weight in the genome (L437)
+                    zero_w |= rep && bad;
+                    const bool use = rep && !bad && (Iw == Iw);
+                    // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level;
+                    // ln Iw - ln Ig (two logs of magnitude ~6) would cost a digit
+                    const double t = Iw * log_pos(div_exact(Iw, Ig));
+                    accw += to_fix(use ? Iw : 0.0);
+                    accg += to_fix(use ? Ig : 0.0);
+                    const Fix128 tq = to_fix(use ? fabs(t) : 0.0);
+                    acct += (t < 0.0) ? -tq : tq;
                 }
             };
-            if (plain) stage4(std::true_type{}); else stage4(std::false_type{});
+            if (n_orph <= 4) stage4(std::true_type{}); else stage4(std::false_type{});
             if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
-            block_sum2<NW>(accw, accg, scratch_base, tid);          // sumWindowIVOM of both sides (L450)
-            const double Sw = fix_to_double(accw), Sg = fix_to_double(accg);
-            STOP_AFTER(4, Sw + Sg)
-
-            // ---- stage 5: normalise (L453-454), accumulate the divergence (L465-470), re-zero own bins -------
-            Fix128 acck = 0, accn = 0;
-            const double LN2 = 0.69314718055994530942;      // math.log(x, 2) == log(x) / log(2.0)
-#pragma unroll
-            for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
-                if (ITS > 0 && it * NT >= n) continue;
-                const bool rep = (repmask >> it) & 1ull;
-                if (ITS == 0 && !rep) continue;
-                double Iw, Ig;
-                if (ITS > 0) { Iw = iw_keep[it]; Ig = ig_keep[it]; }
-                else { const uint32_t code = code16_at(it) >> kshift; Iw = window_ivom(code, std::false_type{}); Ig = P.ig[code]; }
-                const double pw = div_exact(Iw, Sw);                        // L453-454
-                const double pg = div_exact(Ig, Sg);
-                const double t = pw * div_exact(log_pos(div_exact(pw, pg)), LN2);   // L470
-                // skipped terms: non-representatives, zero-weight max-mers (window flagged), and Pg == 0 (L469)
-                const bool use = rep && (Ig == Ig) && (Iw == Iw) && (pg != 0.0);
-                const Fix128 tq = to_fix(fabs(use ? t : 0.0));
-                acck += (t < 0.0) ? -tq : tq;
-            }
-            if (ITS == 0) __syncthreads();                  // the generic path re-read the tables just now
+            block_sum3<NW>(accw, accg, acct, scratch_base, tid);
             const uint32_t flags_lds = misc[M_FLAGS];
-            zero_own_bins();                                // nobody reads the max-mer table any more
-            block_sum2<NW>(acck, accn, scratch_base + NW * 4, tid);
-            const double acc = fix_to_double(acck);
+            zero_own_bins();                                // behind the barrier: nobody reads the max-mer table any more
+            const double Sw = fix_to_double(accw), Sg = fix_to_double(accg), Tt = fix_to_double(acct);
+            STOP_AFTER(4, Sw + Sg + Tt)
+            // KLD = sum Pw log2(Pw/Pg) = (T/Sw - ln Sw + ln Sg) / ln 2            (L453-454, L465-470)
+            const double LN2 = 0.69314718055994530942;
+            const double acc = (nvalid_top == 0) ? 0.0 : ((Tt / Sw - log(Sw)) + log(Sg)) / LN2;
 
             clear_small();                                  // all reads of the small tables are behind the barrier
             if (tid == 0) {
