@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="scale every scaffold length of the shard (testing only; 1.0 = the named workload)")
-    ap.add_argument("--cpu-windows", type=int, default=48, help="windows in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=150, help="windows in the CPU-baseline sample, ~0.1 s each (0 = skip)")
     opts = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
