@@ -63,6 +63,13 @@ def lib():
                 "%s not found: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "frisk_amd has no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP/HSA runtime; libfrisk_hip.so links the system one under the same
+        # SONAME.  Whichever is loaded first serves both, and torch cannot see the GPU behind the system
+        # runtime ("No HIP GPUs are available") - so when torch is installed, let it load its runtime first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol

@@ -55,6 +55,11 @@ def test_pack_roundtrip_all_bytes():
     (3, 5, 777, 100, False, False),
     (8, 8, 5000, 2500, False, False),
     (1, 1, 600, 600, False, False),
+    (7, 8, 3000, 1500, False, False),     # no small tables at all (orders 7, 8 only)
+    (6, 8, 3000, 1500, False, False),     # small table = order 6 only, no shared prefix
+    (5, 7, 2000, 1000, False, False),     # shared prefix = the lowest order
+    (6, 6, 1500, 500, False, False),
+    (2, 2, 800, 400, False, True),
 ])
 def test_scan_matches_numpy_oracle(kmin, kmax, w, inc, mask_host, rip):
     from frisk_amd import _ffi
