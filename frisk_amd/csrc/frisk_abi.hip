@@ -155,13 +155,13 @@ void plan_scaffold(int64_t size, int32_t w, int32_t inc, bool all, int64_t& ncan
     }
 }
 
-template <bool K8, int ITS, bool DEBUG>
+template <int NT, bool K8, int ITS, bool DEBUG>
 hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st) {
-    auto kern = scan_kernel<K8, ITS, DEBUG>;
+    auto kern = scan_kernel<NT, K8, ITS, DEBUG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(lds));
     if (e != hipSuccess) return e;
-    kern<<<grid, FRISK_SCAN_NT, lds, st>>>(P);
+    kern<<<grid, NT, lds, st>>>(P);
     return hipGetLastError();
 }
 
@@ -536,25 +536,26 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     int64_t chunk = n / (int64_t(grid) * 8);
     chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, 16));
     P.chunk = int32_t(chunk);
-    // unroll depth of the per-position loops: the smallest instantiated ITS with ITS*1024 >= longest window
-    const int64_t need = (c->plan_maxwin + FRISK_SCAN_NT - 1) / FRISK_SCAN_NT;
-    const int its = need <= 2 ? 2 : need <= 5 ? 5 : need <= 8 ? 8 : 0;
+    // fast paths: 512-thread workgroups, per-position loops unrolled ITS = 4 / 10 / 16 times (windows up to 2048 /
+    // 5120 / 8192 bases); anything longer (up to 65535): generic 1024-thread kernel with runtime loops
+    const int64_t need = (c->plan_maxwin + 511) / 512;
+    const int its = need <= 4 ? 4 : need <= 10 ? 10 : need <= 16 ? 16 : 0;
 
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
-#define FRISK_LAUNCH(K8_, ITS_, DBG_) e = launch_scan<K8_, ITS_, DBG_>(P, grid, L.total, c->stream)
+#define FRISK_LAUNCH(NT_, K8_, ITS_, DBG_) e = launch_scan<NT_, K8_, ITS_, DBG_>(P, grid, L.total, c->stream)
     if (k8) {
-        if (debug) { if (its) FRISK_LAUNCH(true, 8, true); else FRISK_LAUNCH(true, 0, true); }
-        else if (its == 2) FRISK_LAUNCH(true, 2, false);
-        else if (its == 5) FRISK_LAUNCH(true, 5, false);
-        else if (its == 8) FRISK_LAUNCH(true, 8, false);
-        else FRISK_LAUNCH(true, 0, false);
+        if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
+        else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
+        else if (its == 10) FRISK_LAUNCH(512, true, 10, false);
+        else if (its == 16) FRISK_LAUNCH(512, true, 16, false);
+        else FRISK_LAUNCH(1024, true, 0, false);
     } else {
-        if (debug) { if (its) FRISK_LAUNCH(false, 8, true); else FRISK_LAUNCH(false, 0, true); }
-        else if (its == 2) FRISK_LAUNCH(false, 2, false);
-        else if (its == 5) FRISK_LAUNCH(false, 5, false);
-        else if (its == 8) FRISK_LAUNCH(false, 8, false);
-        else FRISK_LAUNCH(false, 0, false);
+        if (debug) { if (its) FRISK_LAUNCH(512, false, 16, true); else FRISK_LAUNCH(1024, false, 0, true); }
+        else if (its == 4) FRISK_LAUNCH(512, false, 4, false);
+        else if (its == 10) FRISK_LAUNCH(512, false, 10, false);
+        else if (its == 16) FRISK_LAUNCH(512, false, 16, false);
+        else FRISK_LAUNCH(1024, false, 0, false);
     }
 #undef FRISK_LAUNCH
     HIPC(c, e);

@@ -4,7 +4,8 @@
 //   crawlGenome (L194-251) -> computeKmers(window) (L280-367) -> IvomBuild(genome side) + IvomBuild(window
 //   side) (L369-457) -> KLD (L459-472) -> calcGC (L120-137) [-> calcRIP (L474-495)].
 //
-// Mapping onto CDNA4: one 1024-thread workgroup (16 wavefronts) owns one window at a time and keeps the
+// Mapping onto CDNA4: one workgroup (512 threads = 8 wavefronts on the unrolled fast paths) owns one window at a
+// time and keeps the
 // window's k-mer histograms in LDS as dense 16-bit counters (two per dword, updated with 32-bit ds_add):
 //   * every position does ONE update of the "small" tables (orders kmin..6, or kmin..K when K <= 7): to the
 //     table of order r = min(run, top) at the code of its longest valid word; lower orders then follow by an
@@ -26,17 +27,18 @@
 //     one pass over the max-mers, no normalisation pass.
 // Same mathematics, different rounding: |KLD - reference| stays below ~1e-13 (north-star bound 1e-6; the parity
 // tests assert 1e-11 / 1e-10).  The oracles keep the reference's operation order.
-// With only 4 wavefronts per SIMD (the 128 KiB table allows one workgroup per CU) latency has to be hidden
-// inside each wavefront: the per-position loops are fully unrolled (ITS iterations, a template parameter),
-// loads and table gathers are unconditional and issued ahead of their use, and every position of a lane is
-// evaluated in straight-line code (non-representatives are masked out when accumulating).
+// The 128 KiB table allows one workgroup per CU, and the scoring code wants ~200 VGPRs per lane to keep several
+// positions' division/log chains in flight, so the fast paths run 512 threads (2 wavefronts per SIMD, 256 VGPRs
+// available) with the per-position loops fully unrolled (ITS iterations, a template parameter): loads are
+// unconditional and issued ahead of their use, every position of a lane is evaluated in straight-line code
+// (non-representatives are masked out when accumulating).  Measured: same speed as 1024 threads at 128 VGPRs
+// for identical code - and room for the cheaper exact summation below, which spills at 128 VGPRs.
 // FP64 throughout (the terms cancel from O(1) to O(1e-2)).  No MFMA: this is histogramming + scalar arithmetic.
 #pragma once
 #include <type_traits>
 
 #include "frisk_device.h"
 
-#define FRISK_SCAN_NT 1024
 #define FRISK_T8_BYTES 131072
 
 struct ScanParams {
@@ -193,41 +195,28 @@ __device__ inline double log_pos(double x) {
 }
 
 // ---- order-independent summation ---------------------------------------------------------------------
-// Which lane becomes the representative of a max-mer depends on the arrival order of LDS atomics, so a
-// floating-point sum over representatives would depend on timing.  Every per-window sum (the two IVOM
-// normalisers and the divergence) is therefore accumulated as a 128-bit two's-complement integer in units of
-// 2^-84 (four 32-bit limbs).  |term| < 2^11 and a window has < 2^16 max-mers, so |sum| < 2^27 * 2^84 < 2^127.
-// A term is cut into three 32-bit limbs (bits 2^-84 .. 2^11): 12 instructions, exact for every double whose
-// last mantissa bit is >= 2^-84, truncated below that (a fixed, order-independent function of the term).
-// Integer addition is associative, so results are bit-identical across runs, builds, grids and GPUs.
-typedef __int128 Fix128;        // units of 2^-84
+// Which lane becomes the representative of a max-mer depends on the arrival order of LDS atomics, so an ordinary
+// floating-point sum over representatives would depend on timing.  Every per-window sum is therefore accumulated
+// as a PAIR of doubles whose additions are exact, hence associative:
+//   hi = the term rounded to a multiple of 2^-26   ((x + 1.5*2^26) - 1.5*2^26, round-to-nearest-even)
+//   lo = the remainder (exact, |lo| <= 2^-27) rounded to a multiple of 2^-64
+// |term| < 2^11 and a window has < 2^16 max-mers, so every partial sum of hi's is a multiple of 2^-26 below 2^27 and
+// every partial sum of lo's a multiple of 2^-64 below 2^-11: both fit the 53-bit mantissa, no addition ever rounds.
+// The per-term rounding at 2^-64 is a fixed function of the term.  Results are therefore bit-identical across
+// runs, builds, grids and GPUs, at 7 FP64 instructions per term (a 128-bit integer accumulator cost 18).
+struct ExactSum {
+    double hi, lo;
+};
 
-// the three 32-bit limbs of m >= 0 (bits 2^11 .. 2^-84), as one 96-bit integer
-__device__ inline Fix128 to_fix(double m) {
-    const double s1 = m * 0x1p20;                           // exact scalings and remainders
-    const uint32_t a1 = uint32_t(s1);                       // truncation = floor (m >= 0)
-    const double s2 = (s1 - double(a1)) * 0x1p32;
-    const uint32_t a2 = uint32_t(s2);
-    const double s3 = (s2 - double(a2)) * 0x1p32;
-    const uint32_t a3 = uint32_t(s3);
-    return (Fix128(a1) << 64) | Fix128((uint64_t(a2) << 32) | a3);
+__device__ inline void exact_add(ExactSum& a, double x) {
+    const double C1 = 0x1.8p26, C2 = 0x1.8p-12;             // 1.5 * 2^(52-26),  1.5 * 2^(52-64)
+    const double h = (x + C1) - C1;
+    const double l = ((x - h) + C2) - C2;
+    a.hi += h;
+    a.lo += l;
 }
 
-__device__ inline double fix_to_double(Fix128 a) {
-    // sign-magnitude: converting the two's-complement limbs of a negative sum directly would add small limbs to
-    // ~2^12 before the top limb cancels it, losing everything below 2^-41
-    const bool neg = a < 0;
-    const unsigned __int128 m = neg ? (unsigned __int128)(-a) : (unsigned __int128)a;
-    const uint32_t l3 = uint32_t(m), l2 = uint32_t(m >> 32), l1 = uint32_t(m >> 64), l0 = uint32_t(m >> 96);
-    const double v = ((double(l3) * 0x1p-84 + double(l2) * 0x1p-52) + double(l1) * 0x1p-20) + double(l0) * 0x1p12;
-    return neg ? -v : v;
-}
-
-__device__ inline Fix128 fix_shfl_down(Fix128 a, int o) {
-    const uint64_t lo = __shfl_down((unsigned long long)uint64_t(a), o);
-    const uint64_t hi = __shfl_down((unsigned long long)uint64_t(a >> 64), o);
-    return Fix128((unsigned __int128)lo | ((unsigned __int128)hi << 64));
-}
+__device__ inline double exact_value(const ExactSum& a) { return a.hi + a.lo; }
 
 // n / d for operands whose quotient needs no exponent scaling (here: positive integers < 2^53 as doubles, and
 // ratios of normal probabilities): the same reciprocal refinement + residual correction the compiler emits for
@@ -247,36 +236,33 @@ __device__ inline double div_exact(double n, double d) {
 // sum three accumulators over the workgroup; every thread returns the same totals.  One barrier: the scratch is
 // rewritten only after the window's last barrier.
 template <int NW>
-__device__ inline void block_sum3(Fix128& a, Fix128& b, Fix128& c, uint64_t* scratch, int tid) {
+__device__ inline void block_sum3(ExactSum& a, ExactSum& b, ExactSum& c, double* scratch, int tid) {
     for (int o = 32; o > 0; o >>= 1) {
-        a += fix_shfl_down(a, o);
-        b += fix_shfl_down(b, o);
-        c += fix_shfl_down(c, o);
+        a.hi += __shfl_down(a.hi, o); a.lo += __shfl_down(a.lo, o);
+        b.hi += __shfl_down(b.hi, o); b.lo += __shfl_down(b.lo, o);
+        c.hi += __shfl_down(c.hi, o); c.lo += __shfl_down(c.lo, o);
     }
     if ((tid & 63) == 0) {
-        uint64_t* p = scratch + (tid >> 6) * 6;
-        p[0] = uint64_t(a); p[1] = uint64_t(a >> 64); p[2] = uint64_t(b); p[3] = uint64_t(b >> 64);
-        p[4] = uint64_t(c); p[5] = uint64_t(c >> 64);
+        double* p = scratch + (tid >> 6) * 6;
+        p[0] = a.hi; p[1] = a.lo; p[2] = b.hi; p[3] = b.lo; p[4] = c.hi; p[5] = c.lo;
     }
     __syncthreads();
-    Fix128 sa = 0, sb = 0, sc = 0;
+    ExactSum sa = {0.0, 0.0}, sb = {0.0, 0.0}, sc = {0.0, 0.0};
     for (int w = 0; w < NW; ++w) {
-        const uint64_t* p = scratch + w * 6;
-        sa += Fix128((unsigned __int128)p[0] | ((unsigned __int128)p[1] << 64));
-        sb += Fix128((unsigned __int128)p[2] | ((unsigned __int128)p[3] << 64));
-        sc += Fix128((unsigned __int128)p[4] | ((unsigned __int128)p[5] << 64));
+        const double* p = scratch + w * 6;
+        sa.hi += p[0]; sa.lo += p[1]; sb.hi += p[2]; sb.lo += p[3]; sc.hi += p[4]; sc.lo += p[5];
     }
     a = sa;
     b = sb;
     c = sc;
 }
 
+// NT: threads per workgroup.
 // ITS > 0: the window has at most ITS*NT positions; per-position loops are fully unrolled and the per-position
 //          codes and IVOM values stay in registers between the passes.
 // ITS == 0: any length up to 65535; runtime loops, values recomputed in the last pass.
-template <bool K8, int ITS, bool DEBUG>
-__global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P) {
-    constexpr int NT = FRISK_SCAN_NT;
+template <int NT, bool K8, int ITS, bool DEBUG>
+__global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
     constexpr int NW = NT / 64;
     constexpr int NREG = ITS > 0 ? ITS : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -294,7 +280,7 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
     double* rtab = reinterpret_cast<double*>(lds + L.rtab);
     using wsum_t = typename std::conditional<(ITS > 0), uint32_t, unsigned long long>::type;   // W < 2^32 for n <= 8192
     uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L.misc);
-    uint64_t* scratch_base = reinterpret_cast<uint64_t*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
+    double* scratch_base = reinterpret_cast<double*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
     const int ks = K8 ? 6 : kmax;                       // highest order kept in the small tables
     const int lv = shared_level(kmin, kmax);            // recursion shared up to this order (0: not shared)
     const int kshift = 16 - 2 * kmax;
@@ -560,11 +546,13 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
 
             // ---- stage 4: every max-mer position of the lane: window-side IVOM (closed form), genome side from the
             // table, and the three sums  Sw = sum Iw,  Sg = sum Ig,  T = sum Iw ln(Iw/Ig)  over representatives
-            auto window_ivom = [&](uint32_t code, auto plain_c) -> double {
-                constexpr bool PLAIN = decltype(plain_c)::value;            // <= 4 orphans: no list loop in count(7)
+            // plain_c: <= 4 orphans (no list loop in count(7));  lv_c: the shared prefix table is in use.  Both are
+            // window-uniform and resolved OUTSIDE the per-position loop so that its unrolled body is one basic block.
+            auto window_ivom = [&](uint32_t code, auto plain_c, auto lv_c, double& A_out) __attribute__((always_inline)) -> double {
+                constexpr bool PLAIN = decltype(plain_c)::value;
                 wsum_t W = 0;
                 double A = 0.0;
-                if (lv) {
+                if constexpr (decltype(lv_c)::value) {
                     constexpr int LV = 5;                                   // == shared_level() whenever it is not 0
                     const uint32_t pc = code >> (2 * (kmax - LV));
                     W = pre_w[pc];
@@ -578,17 +566,18 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                     }
                 } else {
                     for (int x = kmin; x <= kmax; ++x) {
-                        const uint32_t cx = T.count(x, code >> (2 * (kmax - x)));
+                        const uint32_t cx = T.template count<PLAIN>(x, code >> (2 * (kmax - x)));
                         const double cd = double(cx);
                         W += wsum_t(cx) << (2 * x);
                         A = __builtin_fma(cd * cd, rtab[x], A);
                     }
                 }
-                return div_exact(A, double(W));
+                A_out = A;
+                return double(W);
             };
-            Fix128 accw = 0, accg = 0, acct = 0;
+            ExactSum accw = {0.0, 0.0}, accg = {0.0, 0.0}, acct = {0.0, 0.0};
             bool zero_w = false;
-            auto stage4 = [&](auto plain_c) {
+            auto stage4 = [&](auto plain_c, auto lv_c) __attribute__((always_inline)) {
 #pragma unroll
                 for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
                     // (iterations past the window are not skipped: their lanes are clamped and masked, and a
@@ -597,25 +586,37 @@ __global__ __launch_bounds__(FRISK_SCAN_NT) void scan_kernel(const ScanParams P)
                     if (ITS == 0 && !rep) continue;
                     const uint32_t code = code16_at(it) >> kshift;
                     const double Ig = P.ig[code];                           // unconditional gather (code < 4^K always)
-                    const double Iw = window_ivom(code, plain_c);
+                    // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
+                    double A;
+                    const double Wd = window_ivom(code, plain_c, lv_c, A);
                     const bool bad = (Ig != Ig);                            // zero weight in the genome (L437)
                     zero_w |= rep && bad;
+                    const double ratio = div_exact(A, Wd * Ig);
+                    const double Iw = ratio * Ig;
                     const bool use = rep && !bad && (Iw == Iw);
-                    // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level;
-                    // ln Iw - ln Ig (two logs of magnitude ~6) would cost a digit
-                    const double t = Iw * log_pos(div_exact(Iw, Ig));
-                    accw += to_fix(use ? Iw : 0.0);
-                    accg += to_fix(use ? Ig : 0.0);
-                    const Fix128 tq = to_fix(use ? fabs(t) : 0.0);
-                    acct += (t < 0.0) ? -tq : tq;
+                    // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
+                    const double t = Iw * log_pos(ratio);
+                    exact_add(accw, use ? Iw : 0.0);
+                    exact_add(accg, use ? Ig : 0.0);
+                    exact_add(acct, use ? t : 0.0);
+#ifndef FRISK_S4_GROUP
+#define FRISK_S4_GROUP 2
+#endif
+                    // interleave at most FRISK_S4_GROUP positions: more overlap needs more live registers than the
+                    // 128 a 1024-thread workgroup leaves per lane, and the scheduler would spill
+                    if ((it % FRISK_S4_GROUP) == FRISK_S4_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (n_orph <= 4) stage4(std::true_type{}); else stage4(std::false_type{});
+            if (lv) {
+                if (n_orph <= 4) stage4(std::true_type{}, std::true_type{}); else stage4(std::false_type{}, std::true_type{});
+            } else {
+                if (n_orph <= 4) stage4(std::true_type{}, std::false_type{}); else stage4(std::false_type{}, std::false_type{});
+            }
             if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
             block_sum3<NW>(accw, accg, acct, scratch_base, tid);
             const uint32_t flags_lds = misc[M_FLAGS];
             zero_own_bins();                                // behind the barrier: nobody reads the max-mer table any more
-            const double Sw = fix_to_double(accw), Sg = fix_to_double(accg), Tt = fix_to_double(acct);
+            const double Sw = exact_value(accw), Sg = exact_value(accg), Tt = exact_value(acct);
             STOP_AFTER(4, Sw + Sg + Tt)
             // KLD = sum Pw log2(Pw/Pg) = (T/Sw - ln Sw + ln Sg) / ln 2            (L453-454, L465-470)
             const double LN2 = 0.69314718055994530942;
