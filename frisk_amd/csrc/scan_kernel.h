@@ -347,11 +347,13 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             parity ^= 1u;
 
             // ---- stage 1: one pass over the window's positions ------------------------------------------
-            //   * uppercase base composition (calcGC L120-137, countN L106-118) by wave ballots
+            //   * uppercase base composition (calcGC L120-137, countN L106-118): order-1 counts minus the soft-masked
+            //     bases (wave ballots only where a wave meets lowercase; full ballots when kmin > 1)
             //   * ONE small-table update per position + the max-mer update that elects representatives
-            // (done before the N filter is known: 93 % of windows pass it, the others are cleaned up below)
+            // (done before the N filter is known: 93 % of windows pass it, the others are cleaned up after stage 2)
             unsigned long long repmask = 0;
             uint32_t c16v[NREG];
+            const bool tally_by_ballot = (kmin != 1);
             {
                 uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
 #pragma unroll
@@ -397,10 +399,20 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                             }
                         }
                     }
-                    cA += __popcll(__ballot(up && c2 == 0));
-                    cT += __popcll(__ballot(up && c2 == 1));
-                    cG += __popcll(__ballot(up && c2 == 2));
-                    cC += __popcll(__ballot(up && c2 == 3));
+                    if (tally_by_ballot) {          // kmin > 1: no order-1 table to read the composition from
+                        cA += __popcll(__ballot(up && c2 == 0));
+                        cT += __popcll(__ballot(up && c2 == 1));
+                        cG += __popcll(__ballot(up && c2 == 2));
+                        cC += __popcll(__ballot(up && c2 == 3));
+                    } else {                        // count only the soft-masked valid bases (rare): upper = C_1 - these
+                        const bool lowv = act && low1 && !(inv8 >> 7);
+                        if (__ballot(lowv)) {
+                            cA += __popcll(__ballot(lowv && c2 == 0));
+                            cT += __popcll(__ballot(lowv && c2 == 1));
+                            cG += __popcll(__ballot(lowv && c2 == 2));
+                            cC += __popcll(__ballot(lowv && c2 == 3));
+                        }
+                    }
                     nvalid += __popcll(__ballot(is_top));
                 }
                 if (lane == 0) {
@@ -413,7 +425,37 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             }
             __syncthreads();
             if (tid < FRISK_MISC_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
-            const uint32_t upA = misc[M_UPA], upT = misc[M_UPT], upG = misc[M_UPG], upC = misc[M_UPC];
+
+            // ---- stage 2: marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] --------------
+            auto marg_level = [&](int x, int first, int step) {
+                const uint32_t ox = uint32_t(table_offset(kmin, x)), ou = uint32_t(table_offset(kmin, x + 1));
+                for (uint32_t c = first; c < (1u << (2 * x)); c += step) {
+                    const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ou + 4 * c);     // 8-byte aligned
+                    small16[ox + c] = uint16_t(small16[ox + c] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) +
+                                               (ch.y >> 16));
+                }
+            };
+            {
+                int x = ks - 1;
+                for (; x >= kmin && x > 3; --x) {               // wide levels: all waves, one barrier each
+                    marg_level(x, tid, NT);
+                    __syncthreads();
+                }
+                if (x >= kmin) {                                // levels of <= 64 bins: wave 0 alone, in order
+                    if (tid < 64) {
+                        for (; x >= kmin; --x) {
+                            marg_level(x, tid, 64);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            uint32_t upA = misc[M_UPA], upT = misc[M_UPT], upG = misc[M_UPG], upC = misc[M_UPC];
+            if (!tally_by_ballot) {             // kmin == 1: the order-1 table starts the small tables
+                upA = small16[0] - upA; upT = small16[1] - upT; upG = small16[2] - upG; upC = small16[3] - upC;
+            }
             const int64_t S = int64_t(upA) + upT + upG + upC;       // windowSpace (L380)
             const int64_t nn = n - S;                               // nnTotal of the window
             // N filter (L237-241 / L213): dropped when nn >= 0.3 * len, evaluated in double like CPython
@@ -455,32 +497,6 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             }
             STOP_AFTER(1, small16[tid & 3] + nvalid_top)
 
-            // ---- stage 2: marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] --------------
-            auto marg_level = [&](int x, int first, int step) {
-                const uint32_t ox = uint32_t(table_offset(kmin, x)), ou = uint32_t(table_offset(kmin, x + 1));
-                for (uint32_t c = first; c < (1u << (2 * x)); c += step) {
-                    const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ou + 4 * c);     // 8-byte aligned
-                    small16[ox + c] = uint16_t(small16[ox + c] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) +
-                                               (ch.y >> 16));
-                }
-            };
-            {
-                int x = ks - 1;
-                for (; x >= kmin && x > 3; --x) {               // wide levels: all waves, one barrier each
-                    marg_level(x, tid, NT);
-                    __syncthreads();
-                }
-                if (x >= kmin) {                                // levels of <= 64 bins: wave 0 alone, in order
-                    if (tid < 64) {
-                        for (; x >= kmin; --x) {
-                            marg_level(x, tid, 64);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
             STOP_AFTER(2, small16[tid & 3] + nvalid_top)
 
             WinTables<K8> T;
