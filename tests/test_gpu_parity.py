@@ -60,6 +60,8 @@ def test_pack_roundtrip_all_bytes():
     (5, 7, 2000, 1000, False, False),     # shared prefix = the lowest order
     (6, 6, 1500, 500, False, False),
     (2, 2, 800, 400, False, True),
+    (1, 8, 12000, 4000, False, True),     # longer than the unrolled fast paths: generic kernel
+    (1, 6, 30000, 10000, False, False),
 ])
 def test_scan_matches_numpy_oracle(kmin, kmax, w, inc, mask_host, rip):
     from frisk_amd import _ffi
@@ -75,7 +77,7 @@ def test_scan_matches_numpy_oracle(kmin, kmax, w, inc, mask_host, rip):
         assert np.array_equal(gsym, sym) and (tl, ex, nn) == tuple(meta)
         res = e.scan(w, inc, rip=rip and kmin <= 2 <= kmax)
         kept = np.nonzero(res.kept)[0]
-        assert len(kept) == len(rows) and len(rows) > 20
+        assert len(kept) == len(rows) and len(rows) > 10
         worst = 0.0
         for r, exp in zip(kept.tolist(), rows):
             assert (str(res.seq_index[r]), int(res.start[r]), int(res.stop[r])) == (exp["name"], exp["start"], exp["stop"])
