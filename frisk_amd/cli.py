@@ -149,7 +149,7 @@ def main(argv=None):
     querySeq = args.querySeq or args.hostSeq
     if rank == 0 and not os.path.isdir(os.path.abspath(args.tempDir)):
         os.makedirs(os.path.abspath(args.tempDir))
-    for opt, why in (("runProjection", "sklearn projection is out of scope"),
+    for opt, why in (("cluster", "sklearn clustering is out of scope"),
                      ("graphics", "plotting is out of scope"), ("gffIn", "bedtools intersections are out of scope")):
         if getattr(args, opt):
             log.warning("--%s is not available in this build: %s", opt, why)
@@ -217,6 +217,21 @@ def main(argv=None):
         with open(os.path.join(args.tempDir, args.hmmOutfile), "w") as fh:
             for line in hmmBED2GFF(intervals):
                 fh.write(line)
+    if args.runProjection:                                              # L1556-1596: counts for the projection
+        from .fasta import readFasta
+        from .projection import symmetricCounts
+        feats, _ = pp.thresholdKLD(rows, threshold, args, merge=(args.dimReduce == "features"))
+        names, seqs = readFasta(querySeq)
+        fasta = dict(zip(names, seqs))
+        labelled = [(":".join([f[0], str(f[1]), str(f[2])]), fasta[f[0]][int(f[1]) - 1:int(f[2])]) for f in feats if f[0] in fasta]
+        anomLabels, anomCounts = symmetricCounts(labelled, args.pcaMin, args.pcaMax, device=local_rank)
+        if args.dumpPCAdata:
+            with open(os.path.join(args.tempDir, "anomLabels"), "wb") as fh:
+                pickle.dump(anomLabels, fh, protocol=2)
+            with open(os.path.join(args.tempDir, "anomCounts"), "wb") as fh:
+                pickle.dump(anomCounts, fh, protocol=2)
+        log.info("Symmetric k-mer proportions of %s anomalous windows computed; the %s projection is not built here.",
+                 len(labelled), args.runProjection)
     anomalies, _sel = pp.thresholdKLD(rows, threshold, args, merge=True)
     log.info("Detected %s features above KLD threshold.", len(anomalies))
     if args.gffOutfile:

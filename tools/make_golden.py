@@ -42,7 +42,8 @@ REF_SRC = "/root/reference/frisk/__init__.py"
 HOT_FUNCS = ["countN", "calcGC", "iterFasta", "crawlGenome", "prepareMaps", "rangeMaps",
              "revComplement", "computeKmers", "IvomBuild", "KLD", "calcRIP", "makePicklePath",
              "FDBins", "otsu", "setKLDThresh", "natural_sort",      # row f1 (thresholds), host-side numpy
-             "mainArgs"]                                            # the argparse surface (row f2)
+             "mainArgs",                                            # the argparse surface (row f2)
+             "scrubMirrors", "flattenKmerMap"]                      # symmetric counts for the projection (row f4)
 
 
 def load_reference_functions():
@@ -230,6 +231,30 @@ def run_thresholds(ns):
     print("thresholds      ", {k: (v["FDBins"], v["otsu"]) for k, v in out.items() if isinstance(v, dict)})
 
 
+def run_projection_counts(ns):
+    """Row f4: computeKmers(sym=True, pcaMode=True) -> scrubMirrors -> flattenKmerMap(prop=True) (L1571-1591) on a few
+    windows of a fixture."""
+    class A:
+        pcaMin, pcaMax, minWordSize, maxWordSize, maskHost, hostSeq = 1, 4, 1, 8, False, None
+    recs = list(ns["iterFasta"](os.path.join(INP, "markov_islands.fa")))
+    seq = recs[0][1]
+    wins = [("chrA:%d:%d" % (a + 1, b), seq[a:b]) for a, b in ((0, 400), (380, 800), (2200, 2600), (2690, 3090))]
+    blank = ns["rangeMaps"](A.pcaMin, A.pcaMax)
+    out = {"pcaMin": A.pcaMin, "pcaMax": A.pcaMax, "windows": [], "keys": None}
+    for name, target in wins:
+        cm = ns["computeKmers"](A, genomepickle=None, window=[(name, target)], genomeMode=False, pcaMode=True,
+                                kmerMap=blank, getMeta=False, sym=True)
+        uniq = ns["scrubMirrors"](cm)
+        vec = ns["flattenKmerMap"](uniq, window=400, seqLen=len(target), kmin=A.pcaMin, kmax=A.pcaMax, prop=True)
+        if out["keys"] is None:
+            out["keys"] = [k for d in uniq for k in d.keys()]
+        out["windows"].append({"label": name, "seq": target, "vector": [float(v) for v in vec]})
+    with open(os.path.join(GOLD, "projection_counts.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+        fh.write("\n")
+    print("projection_counts %d windows x %d features" % (len(out["windows"]), len(out["keys"])))
+
+
 def run_cli_surface(ns):
     """Row f2: every option of the reference's parser (L1130-1393): flags, dest, default, type, choices, nargs,
     action, required.  mainArgs() parses sys.argv at its end; parse_args is intercepted to get the parser."""
@@ -275,6 +300,8 @@ def main():
         run_thresholds(ns)
     if not opts.cases or "cli_surface" in opts.cases:
         run_cli_surface(ns)
+    if not opts.cases or "projection_counts" in opts.cases:
+        run_projection_counts(ns)
 
 
 if __name__ == "__main__":
