@@ -24,6 +24,10 @@ SYMBOLS = [
     ("frisk_last_error", C.c_char_p, [_P]),
     ("frisk_profile_len", C.c_int64, [_P]),
     ("frisk_seq_load", C.c_int, [_P, C.POINTER(C.c_char_p), _I64P, C.c_int32]),
+    ("frisk_fasta_load", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32), _I64P]),
+    ("frisk_seq_count", C.c_int32, [_P]),
+    ("frisk_seq_name", C.c_char_p, [_P, C.c_int32]),
+    ("frisk_seq_len", C.c_int64, [_P, C.c_int32]),
     ("frisk_seq_synth", C.c_int, [_P, _I64P, C.c_int32, C.c_uint64, C.c_double, C.c_double, C.c_double]),
     ("frisk_seq_read", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("frisk_profile_reset", C.c_int, [_P]),

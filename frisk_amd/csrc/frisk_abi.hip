@@ -1,6 +1,7 @@
 // frisk_abi.hip - host side of libfrisk_hip.so: the C ABI declared in include/frisk_hip.h.
 // gfx950 (MI355X) only.  Build: see __graft_entry__.build().
 #include <hip/hip_runtime.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cmath>
@@ -49,6 +50,7 @@ struct frisk_ctx {
     // resident batch
     int32_t n_seq = 0;
     std::vector<int64_t> seq_off, seq_len;
+    std::vector<std::string> seq_name;
     int64_t padded_len = 0;
     bool have_seq = false;
     DevBuf<uint8_t> d_ascii;
@@ -130,6 +132,7 @@ int layout_batch(frisk_ctx* c, const int64_t* lens, int32_t n_seq) {
     if (n_seq < 0) return fail(c, FRISK_E_ARG, "n_seq < 0");
     c->seq_off.assign(size_t(n_seq), 0);
     c->seq_len.assign(lens, lens + n_seq);
+    c->seq_name.assign(size_t(n_seq), std::string());
     int64_t pos = 0;
     for (int32_t s = 0; s < n_seq; ++s) {
         if (lens[s] < 0) return fail(c, FRISK_E_ARG, "negative scaffold length");
@@ -274,6 +277,92 @@ int frisk_seq_load(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens
     rc = alloc_packed(c);
     if (rc) return rc;
     return run_pack(c);
+}
+
+int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t* total_len_out) {
+    if (!c || !path) return FRISK_E_ARG;
+    gzFile fh = gzopen(path, "rb");                         // reads plain files too
+    if (!fh) return fail(c, FRISK_E_ARG, std::string("cannot open FASTA file: ") + path);
+    gzbuffer(fh, 1 << 20);
+    // records are appended to `stage` in the upload layout: sequence bytes, then one PAD byte
+    std::vector<uint8_t> stage;
+    std::vector<int64_t> lens;
+    std::vector<std::string> names;
+    std::string line, carry;
+    std::vector<char> buf(1 << 22);
+    bool in_record = false;
+    int64_t cur_len = 0;
+    auto is_space = [](unsigned char ch) { return ch == ' ' || (ch >= 9 && ch <= 13); };       // str.strip() on ASCII
+    auto finish_record = [&]() {
+        if (in_record) { lens.push_back(cur_len); stage.push_back(uint8_t(FRISK_PAD_BYTE)); }
+    };
+    std::string err;
+    auto handle_line = [&](const char* b, const char* e) {
+        while (b < e && is_space((unsigned char)*b)) ++b;
+        while (e > b && is_space((unsigned char)e[-1])) --e;
+        if (b == e) return;                                                 // blank line (L150-151)
+        if (*b == '>') {                                                    // header (L152-157)
+            const char* hb = b;
+            const char* he = e;
+            while (hb < he && *hb == '>') ++hb;                             // line.strip('>')
+            while (he > hb && he[-1] == '>') --he;
+            while (hb < he && is_space((unsigned char)*hb)) ++hb;           // .split()[0]
+            const char* te = hb;
+            while (te < he && !is_space((unsigned char)*te)) ++te;
+            if (te == hb) { if (err.empty()) err = "FASTA header without a name"; return; }    // IndexError in the reference
+            finish_record();
+            names.emplace_back(hb, te);
+            in_record = true;
+            cur_len = 0;
+        } else if (in_record) {                                             // sequence line (L158-160)
+            stage.insert(stage.end(), reinterpret_cast<const uint8_t*>(b), reinterpret_cast<const uint8_t*>(e));
+            cur_len += e - b;
+        }                                                                   // text before the first header is dropped (L157)
+    };
+    for (;;) {
+        const int got = gzread(fh, buf.data(), unsigned(buf.size()));
+        if (got < 0) { gzclose(fh); return fail(c, FRISK_E_ARG, std::string("read error in FASTA file: ") + path); }
+        if (got == 0) break;
+        const char* p = buf.data();
+        const char* end = p + got;
+        while (p < end) {
+            const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
+            if (!nl) { carry.append(p, end); break; }
+            if (!carry.empty()) { carry.append(p, nl); handle_line(carry.data(), carry.data() + carry.size()); carry.clear(); }
+            else handle_line(p, nl);
+            p = nl + 1;
+        }
+    }
+    gzclose(fh);
+    if (!carry.empty()) handle_line(carry.data(), carry.data() + carry.size());
+    finish_record();
+    if (!err.empty()) return fail(c, FRISK_E_ARG, err + ": " + path);
+    if (lens.size() > size_t(0x7FFFFFFF)) return fail(c, FRISK_E_ARG, "too many FASTA records");
+    HIPC(c, hipSetDevice(c->device));
+    int rc = layout_batch(c, lens.data(), int32_t(lens.size()));
+    if (rc) return rc;
+    c->seq_name = names;
+    stage.resize(size_t(c->padded_len), uint8_t(FRISK_PAD_BYTE));          // tail padding up to a multiple of 32
+    HIPC(c, c->d_ascii.reserve(size_t(c->padded_len)));
+    HIPC(c, hipMemcpyAsync(c->d_ascii.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    rc = alloc_packed(c);
+    if (rc) return rc;
+    rc = run_pack(c);
+    if (rc) return rc;
+    int64_t total = 0;
+    for (int64_t v : lens) total += v;
+    if (n_seq_out) *n_seq_out = int32_t(lens.size());
+    if (total_len_out) *total_len_out = total;
+    return FRISK_OK;
+}
+
+int32_t frisk_seq_count(const frisk_ctx* c) { return (c && c->have_seq) ? c->n_seq : 0; }
+const char* frisk_seq_name(const frisk_ctx* c, int32_t s) {
+    return (c && c->have_seq && s >= 0 && s < c->n_seq) ? c->seq_name[size_t(s)].c_str() : "";
+}
+int64_t frisk_seq_len(const frisk_ctx* c, int32_t s) {
+    return (c && c->have_seq && s >= 0 && s < c->n_seq) ? c->seq_len[size_t(s)] : -1;
 }
 
 int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t seed, double island_frac,

@@ -4,6 +4,7 @@ Thin host plumbing over the C ABI (include/frisk_hip.h); all arithmetic of the h
 the HIP kernels.  torch is used only by `profile_allreduce` (RCCL through torch.distributed).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -114,6 +115,15 @@ class Engine:
         self._check(self._lib.frisk_seq_load(self._ctx, arr, lens, n))
         self.n_seq = n
         self.seq_lens = [len(b) for b in bufs]
+
+    def load_fasta(self, path):
+        """Parse a FASTA / FASTA.gz file in the library (no Python per-line loop) and make its records resident.
+        Returns the record names."""
+        n, total = C.c_int32(), C.c_int64()
+        self._check(self._lib.frisk_fasta_load(self._ctx, os.fsencode(path), C.byref(n), C.byref(total)))
+        self.n_seq = int(n.value)
+        self.seq_lens = [int(self._lib.frisk_seq_len(self._ctx, i)) for i in range(self.n_seq)]
+        return [self._lib.frisk_seq_name(self._ctx, i).decode("ascii", "replace") for i in range(self.n_seq)]
 
     def synth(self, lens, seed, island_frac=0.02, n_frac=0.0, lower_frac=0.0):
         lens = [int(x) for x in lens]

@@ -14,7 +14,6 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine, table_offset
-from .fasta import readFasta
 
 LETTERS = ("A", "T", "G", "C")      # reference L70
 
@@ -64,8 +63,7 @@ class HotPath:
 
     def _load(self, path):
         if self._resident != path:
-            self.names, seqs = readFasta(path)
-            self.engine.load(seqs)
+            self.names = self.engine.load_fasta(path)       # native reader (iterFasta semantics, L139-164)
             self._resident = path
 
     # phase A -----------------------------------------------------------------------------------

@@ -66,6 +66,15 @@ int64_t frisk_profile_len(const frisk_ctx* ctx);      /* sum_{x=kmin..kmax} 4^x 
  * next load.  Empty scaffolds (len 0) are allowed. */
 int frisk_seq_load(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq);
 
+/* Native FASTA reader: parse `path` (plain or gzip) with the record semantics of the reference's iterFasta
+ * (L139-164: name = first whitespace-delimited token of the header with '>' stripped from both ends, lines stripped of
+ * surrounding whitespace, blank lines skipped, case preserved) straight into the upload layout, and make its records
+ * the resident batch.  Record names / lengths are then available from frisk_seq_name / frisk_seq_len. */
+int frisk_fasta_load(frisk_ctx* ctx, const char* path, int32_t* n_seq, int64_t* total_len);
+int32_t frisk_seq_count(const frisk_ctx* ctx);
+const char* frisk_seq_name(const frisk_ctx* ctx, int32_t seq_index);   /* "" for batches not loaded from FASTA */
+int64_t frisk_seq_len(const frisk_ctx* ctx, int32_t seq_index);
+
 /* Bench/test utility: fill the resident batch with synthetic scaffolds generated ON the device
  * (order-3 Markov background + compositional islands + N runs + soft-masked runs; the generator
  * is specified in frisk_amd/synth.py, which reproduces it bit-for-bit on the host). */

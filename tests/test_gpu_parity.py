@@ -285,3 +285,41 @@ def test_rccl_allreduce_path_single_rank():
         sym, tl, ex, nn = e.profile_get()
         osym, ometa = N.genome_profile(seqs, 1, 8)
         assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+
+
+def test_native_fasta_reader_matches_python_reader(tmp_path):
+    """frisk_fasta_load (C++, zlib) against frisk_amd.fasta.iterFasta (the restated iterFasta, L139-164)."""
+    import gzip
+    import os
+    from frisk_amd import _ffi
+    from frisk_amd.fasta import readFasta
+    from golden_util import INPUTS
+
+    def canon(b):
+        return bytes(c if c in b"ACGTacgt" else ord("N") for c in b)
+
+    tricky = tmp_path / "tricky.fa"
+    tricky.write_bytes(b"stray text before any header\nACGT\n>>r1>  first record   desc >\r\n  ACGTNN  \r\n\r\nac gt\n\n>r2\n>r3\tx\n"
+                       b"TTTTTTTTTT\nGG>GG\n>r4 last no newline\nACGTRYKM")
+    gz = tmp_path / "tricky.fa.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(tricky.read_bytes())
+    big = tmp_path / "big.fa"
+    with open(big, "wb") as fh:                 # > 64 records, long lines, crosses the 4 MiB read buffer
+        for i in range(70):
+            fh.write(b">c%d\n" % i + (b"ACGTTGCAAG" * 30000 if i == 3 else b"ACGTN" * (i + 1)) + b"\n")
+    paths = [str(tricky), str(gz), str(big)] + [os.path.join(INPUTS, f) for f in ("kat.fa", "smalls.fa", "k8.fa")]
+    with make_engine(1, 4) as e:
+        for p in paths:
+            names = e.load_fasta(p)
+            pn, ps = readFasta(p)
+            assert names == pn, p
+            assert e.seq_lens == [len(s) for s in ps], p
+            for i in (0, len(ps) // 2, len(ps) - 1):
+                assert e.read_seq(i) == canon(ps[i]), (p, i)
+        with pytest.raises(_ffi.FriskHipError):
+            e.load_fasta(str(tmp_path / "missing.fa"))
+        bad = tmp_path / "bad.fa"
+        bad.write_bytes(b">\nACGT\n")
+        with pytest.raises(_ffi.FriskHipError):
+            e.load_fasta(str(bad))

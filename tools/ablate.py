@@ -34,7 +34,7 @@ def main():
         lib = os.path.join(OUT, "lib_%s.so" % spec.replace(",", "_").replace("=", ""))
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
                         "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", lib,
-                        os.path.join(CSRC, "frisk_abi.hip")] + defs, check=True)
+                        os.path.join(CSRC, "frisk_abi.hip"), "-lz"] + defs, check=True)
         env = dict(os.environ, FRISK_HIP_LIB=lib)
         out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, scale)], env=env, capture_output=True, text=True)
         print(spec, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:], flush=True)
