@@ -80,7 +80,7 @@ class GaussianHMM2:
             w = post.sum(axis=0)
             self.means_ = (post * x[:, None]).sum(axis=0) / w
             self.covars_ = (self.covars_prior + (post * (x[:, None] - self.means_[None, :]) ** 2).sum(axis=0)) / w
-            self.covars_ = np.maximum(self.covars_, self.min_covar)
+            self.covars_ = np.maximum(self.covars_, 1e-300)      # (hmmlearn applies min_covar at initialisation only)
             if ll - prev < self.tol:
                 break
             prev = ll
