@@ -323,3 +323,25 @@ def test_native_fasta_reader_matches_python_reader(tmp_path):
         bad.write_bytes(b">\nACGT\n")
         with pytest.raises(_ffi.FriskHipError):
             e.load_fasta(str(bad))
+
+
+def test_many_small_scaffolds():
+    """Hundreds of scaffolds (host staging path of frisk_seq_load, descriptor search in the scan kernel, skipped and
+    rescued small scaffolds in between)."""
+    rng = np.random.default_rng(3)
+    lens = [int(x) for x in rng.integers(200, 9000, size=300)]
+    seqs = synth_seqs(lens, 31, island_frac=0.2, n_frac=0.1, lower_frac=0.05)
+    for rescue in (False, True):
+        (sym, meta), rows = oracle_rows(seqs, 1, 8, 2000, 500, scaffolds_all=rescue)
+        with make_engine(1, 8) as e:
+            e.load(seqs)
+            e.profile_reset(); e.profile_add(); e.profile_finalize()
+            gsym, tl, ex, nn = e.profile_get()
+            assert np.array_equal(gsym, sym) and (tl, ex, nn) == tuple(meta)
+            res = e.scan(2000, 500, scaffolds_all=rescue)
+            kept = np.nonzero(res.kept)[0]
+            assert len(kept) == len(rows) > 500
+            got = [(str(res.seq_index[r]), int(res.start[r]), int(res.stop[r])) for r in kept.tolist()]
+            assert got == [(r["name"], r["start"], r["stop"]) for r in rows]
+            worst = max(abs(float(res.kld[r]) - exp["KLD"]) for r, exp in zip(kept.tolist(), rows))
+            assert worst <= KLD_TOL
