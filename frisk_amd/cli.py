@@ -136,9 +136,11 @@ def main(argv=None):
     args = mainArgs(argv)
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the sharded code path can be forced in a one-rank job (tests rehearse it on a single GPU)
+    sharded = world > 1 or os.environ.get("FRISK_FORCE_SHARDED") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if sharded and not dist.is_initialized():
         import torch
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -160,14 +162,14 @@ def main(argv=None):
     hp = HotPath(args.minWordSize, args.maxWordSize, device=local_rank)
     try:
         # ---- phase A: host k-mer profile (L1436-1447); --recalc is store_false: giving it forces recomputation
-        if os.path.isfile(genomepickle) and args.recalc and world == 1:
+        if os.path.isfile(genomepickle) and args.recalc and not sharded:
             log.info("Importing previously calculated genome kmers from %s", genomepickle)
             with open(genomepickle, "rb") as fh:
                 genomeKmers = pickle.load(fh, encoding="latin1")
             hp.setGenomeProfile(genomeKmers)
         else:
             log.info("Calculating kmers for host sequence: %s", args.hostSeq)
-            if world > 1:
+            if sharded:
                 rows_all = _sharded(hp, args, querySeq, rip)
             else:
                 genomeKmers = hp.genomeProfile(args)
@@ -177,7 +179,7 @@ def main(argv=None):
                 log.info("Finished counting kmers. Exiting.")
                 return 0
         # ---- phase B: window scores (L1454-1507)
-        if world == 1 and os.path.isfile(windowsPickle) and args.recalcWin:
+        if not sharded and os.path.isfile(windowsPickle) and args.recalcWin:
             log.info("Importing previously calculated window KLD scores from: %s", windowsPickle)
             with open(windowsPickle, "rb") as fh:
                 cached = pickle.load(fh)
@@ -188,7 +190,7 @@ def main(argv=None):
             else:
                 rows = [tuple(r) for r in cached["rows"]]
         else:
-            if world > 1:
+            if sharded:
                 rows = rows_all
             else:
                 rows, _ = hp.scanGenome(args, querySeq)

@@ -55,3 +55,24 @@ def test_cli_zero_weight_raises_like_reference(tmp_path):
     with pytest.raises(ZeroDivisionError):
         main(["-H", c.host, "-Q", c.query, "-m", "5", "-k", "6", "-w", "500", "-i", "100", "-t", str(tmp_path / "T"),
               "--exitAfter", "WindowKLD"])
+
+
+def test_cli_sharded_path_in_one_rank_group(tmp_path, capsys, monkeypatch):
+    """The multi-GPU code path of the CLI (run_sharded + RCCL all-reduce + row gather) rehearsed in a one-rank nccl
+    group on a single GPU: same table as the plain path."""
+    import torch.distributed as dist
+    from frisk_amd.cli import main
+    c = Case("smalls_all")
+    argv = ["-H", c.host, "-k", "4", "-w", "400", "-i", "150", "--RIP", "--scaffoldsAll", "--exitAfter", "WindowKLD"]
+    assert main(argv + ["-t", str(tmp_path / "A")]) == 0
+    plain = open(tmp_path / "A" / "raw_window_scores.bed").read()
+    for k, v in (("FRISK_FORCE_SHARDED", "1"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"),
+                 ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29641")):
+        monkeypatch.setenv(k, v)
+    try:
+        assert main(argv + ["-t", str(tmp_path / "B")]) == 0
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    assert open(tmp_path / "B" / "raw_window_scores.bed").read() == plain
+    assert len(plain.splitlines()) == 1 + len(c.rows)
