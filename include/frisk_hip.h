@@ -35,7 +35,7 @@ enum {
     FRISK_E_HIP = -2,         /* a HIP runtime call failed (no device, out of memory, launch failure)  */
     FRISK_E_STATE = -3,       /* call order violated (e.g. scan before a profile is finalised)         */
     FRISK_E_CAP = -4,         /* caller buffer too small; the needed size is reported                  */
-    FRISK_E_ZERO_WEIGHT = -5  /* the reference would raise ZeroDivisionError (L437 / L401-424)         */
+    FRISK_E_ZERO_WEIGHT = -5  /* reserved: ZeroDivisionError cases are reported per row (FRISK_ROW_ZERO_WEIGHT)  */
 };
 
 /* frisk_scan flags */
