@@ -138,6 +138,9 @@ CASES = [
     ("k8_w2000", "k8.fa", None, dict(m=1, k=8, w=2000, i=500), False),
     ("k8_m2", "k8.fa", None, dict(m=2, k=8, w=5000, i=2500, RIP=True), False),
     ("overshoot", "overshoot.fa", None, dict(m=1, k=3, w=100, i=90, RIP=True), False),
+    ("hq_k8", "host.fa", "query.fa", dict(m=1, k=8, w=1000, i=250, RIP=True), False),
+    ("maskhost_k8", "host.fa", None, dict(m=1, k=8, w=2000, i=1000, maskHost=True, scaffoldsAll=True), False),
+    ("hq_m7k8_zero", "host.fa", "query.fa", dict(m=7, k=8, w=1000, i=500), False),
 ]
 
 
