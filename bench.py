@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def cpu_baseline(engine, names_seq0_len, n_windows):
     """Time oracle/frisk_oracle.py (the reference-shaped Python restatement, 1 core) on the first
     `n_windows` candidate windows of scaffold 0, against the profile the GPU just built.
-    Returns (dict for the JSON line, max |KLD_gpu - KLD_oracle| on the sample)."""
+    Returns (dict for the JSON line, max |KLD_gpu - KLD_oracle| on the sample, the numpy oracle's line)."""
     import numpy as np
     from oracle import frisk_oracle as O
     from frisk_amd.hotpath import profileToMaps
@@ -52,12 +52,28 @@ def cpu_baseline(engine, names_seq0_len, n_windows):
             continue
         rows.append(O.score_window(win, gmaps, gmeta, KMIN, KMAX))
     dt = time.perf_counter() - t0
+    # second, separately labelled line: the vectorised numpy restatement on the same windows
+    from oracle import frisk_oracle_np as N
+    ig = N.genome_ivom_table(np.asarray(sym), (tl, ex, nn), KMIN, KMAX)
+    enc = N.Encoded(seq)
+    t1 = time.perf_counter()
+    n_np = 0
+    for j in range(n_windows):
+        win = enc.slice(j * INC, j * INC + W)
+        if (win.n - int(win.upper.sum())) >= 0.3 * win.n:
+            continue
+        N.score_window(win, ig, KMIN, KMAX)
+        n_np += 1
+    dt_np = time.perf_counter() - t1
+    numpy_line = {"value": n_np / dt_np if dt_np > 0 else 0.0, "unit": "windows/s", "cores": 1, "kind": "port",
+                  "sample": "oracle/frisk_oracle_np.py (vectorised numpy restatement, NOT the reference's structure) on the "
+                            "same %d windows; %.2f s" % (n_np, dt_np)}
     kept = np.nonzero(res.kept)[0][:len(rows)]
     worst = max((abs(float(res.kld[r]) - row["KLD"]) for r, row in zip(kept.tolist(), rows)), default=0.0)
     return ({"value": len(rows) / dt if dt > 0 else 0.0, "unit": "windows/s", "cores": 1, "kind": "port",
              "sample": "oracle/frisk_oracle.py (reference-shaped Python, single thread) on the first %d kept "
                        "windows of scaffold 0 of the same synthetic shard, k=%d..%d w=%d i=%d; %.1f s"
-                       % (len(rows), KMIN, KMAX, W, INC, dt)}, worst)
+                       % (len(rows), KMIN, KMAX, W, INC, dt)}, worst, numpy_line)
 
 
 def main():
@@ -159,8 +175,9 @@ def main():
                                  "limits are LDS atomics and FP64 divide/log issue - see DESIGN.md"},
         }
         if opts.cpu_windows > 0:
-            cb, worst = cpu_baseline(eng, lens[0], opts.cpu_windows)
+            cb, worst, np_line = cpu_baseline(eng, lens[0], opts.cpu_windows)
             out["cpu_baseline"] = cb
+            out["cpu_baseline_numpy"] = np_line
             out["cpu_sample_max_abs_dKLD"] = worst
         else:
             out["cpu_baseline"] = None
