@@ -14,6 +14,7 @@ windows), so N = 8 is the full C5 job and N < 8 is the same per-GPU work (weak s
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     - HBM roofline of the dominant kernel (scan): algorithmic bytes / HIP-event kernel time
   cpu_baseline - the reference-shaped Python oracle timed on one host core on a bounded sample
+                 (+ cpu_baseline_numpy, cpu_baseline_c: the vectorised and the compiled multi-thread restatements)
 """
 import argparse
 import json
@@ -32,7 +33,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def cpu_baseline(engine, names_seq0_len, n_windows):
     """Time oracle/frisk_oracle.py (the reference-shaped Python restatement, 1 core) on the first
     `n_windows` candidate windows of scaffold 0, against the profile the GPU just built.
-    Returns (dict for the JSON line, max |KLD_gpu - KLD_oracle| on the sample, the numpy oracle's line)."""
+    Returns (dict for the JSON line, max |KLD_gpu - KLD_oracle| on the sample, the numpy oracle's line, the
+    compiled C oracle's line)."""
     import numpy as np
     from oracle import frisk_oracle as O
     from frisk_amd.hotpath import profileToMaps
@@ -68,12 +70,38 @@ def cpu_baseline(engine, names_seq0_len, n_windows):
     numpy_line = {"value": n_np / dt_np if dt_np > 0 else 0.0, "unit": "windows/s", "cores": 1, "kind": "port",
                   "sample": "oracle/frisk_oracle_np.py (vectorised numpy restatement, NOT the reference's structure) on the "
                             "same %d windows; %.2f s" % (n_np, dt_np)}
+    c_line = cpu_baseline_c(engine, np.asarray(sym), (tl, ex, nn), names_seq0_len)
     kept = np.nonzero(res.kept)[0][:len(rows)]
     worst = max((abs(float(res.kld[r]) - row["KLD"]) for r, row in zip(kept.tolist(), rows)), default=0.0)
     return ({"value": len(rows) / dt if dt > 0 else 0.0, "unit": "windows/s", "cores": 1, "kind": "port",
              "sample": "oracle/frisk_oracle.py (reference-shaped Python, single thread) on the first %d kept "
                        "windows of scaffold 0 of the same synthetic shard, k=%d..%d w=%d i=%d; %.1f s"
-                       % (len(rows), KMIN, KMAX, W, INC, dt)}, worst, numpy_line)
+                       % (len(rows), KMIN, KMAX, W, INC, dt)}, worst, numpy_line, c_line)
+
+
+def cpu_baseline_c(engine, sym, meta, seq0_len, n_windows=60000):
+    """Third, separately labelled CPU line: the compiled C + OpenMP oracle (oracle/frisk_oracle_c.c) on all host
+    threads, on the first `n_windows` candidates of scaffold 0, checked row by row against the GPU."""
+    import numpy as np
+    from oracle import frisk_oracle_c as OC
+    n_windows = min(n_windows, max(0, (seq0_len - W) // INC + 1))
+    if n_windows <= 0:
+        return None
+    span = W + (n_windows - 1) * INC
+    S = OC.Seqs([engine.read_seq(0, 0, span)])
+    ig = OC.genome_ivom(sym, meta, KMIN, KMAX)
+    OC.scan(S, ig, KMIN, KMAX, W, INC, cand=(0, 256))                 # page in, spin the thread pool up
+    t0 = time.perf_counter()
+    exp = OC.scan(S, ig, KMIN, KMAX, W, INC, cand=(0, n_windows))
+    dt = time.perf_counter() - t0
+    res = engine.scan(W, INC, c0=0, c1=n_windows)
+    k = np.nonzero(res.kept)[0]
+    same_rows = len(k) == len(exp["kld"]) and bool(np.array_equal(res.start[k], exp["start"]))
+    worst = float(np.max(np.abs(res.kld[k] - exp["kld"]))) if same_rows and len(k) else float("nan")
+    return {"value": len(exp["kld"]) / dt if dt > 0 else 0.0, "unit": "windows/s", "cores": int(OC.lib().fo_threads()),
+            "kind": "port", "max_abs_dKLD_vs_gpu": worst, "rows_match_gpu": same_rows,
+            "sample": "oracle/frisk_oracle_c.c (compiled C + OpenMP restatement, all host threads) on the first %d "
+                      "candidate windows of scaffold 0 (%d kept); %.2f s" % (n_windows, len(exp["kld"]), dt)}
 
 
 def main():
@@ -175,9 +203,10 @@ def main():
                                  "limits are LDS atomics and FP64 divide/log issue - see DESIGN.md"},
         }
         if opts.cpu_windows > 0:
-            cb, worst, np_line = cpu_baseline(eng, lens[0], opts.cpu_windows)
+            cb, worst, np_line, c_line = cpu_baseline(eng, lens[0], opts.cpu_windows)
             out["cpu_baseline"] = cb
             out["cpu_baseline_numpy"] = np_line
+            out["cpu_baseline_c"] = c_line
             out["cpu_sample_max_abs_dKLD"] = worst
         else:
             out["cpu_baseline"] = None

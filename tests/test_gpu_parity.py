@@ -351,3 +351,47 @@ def test_many_small_scaffolds():
             assert got == [(r["name"], r["start"], r["stop"]) for r in rows]
             worst = max(abs(float(res.kld[r]) - exp["KLD"]) for r, exp in zip(kept.tolist(), rows))
             assert worst <= KLD_TOL
+
+
+@pytest.mark.parametrize("shape", ["C2", "C3", "C4", "C5"])
+def test_full_size_rows_against_c_oracle(shape):
+    """BASELINE configs at full size, row by row against the compiled CPU oracle (oracle/frisk_oracle_c.c, pinned to the
+    reference's golden vectors by tests/test_oracle_c.py): profile bit-exact, kept set / coordinates / GC bit-exact,
+    KLD to 1e-11.  C2..C4: every window.  C5 (3.3 Gb on one GPU): the full profile and three 20 000-candidate slices."""
+    from oracle import frisk_oracle_c as OC
+    from frisk_amd import _ffi, synth
+    if shape == "C2":
+        lens, kmin, kmax, w, inc, nfrac, slices = synth.C2_LENS, 1, 6, 5000, 500, 0.0, [(0, -1)]
+    elif shape == "C3":
+        lens, kmin, kmax, w, inc, nfrac, slices = synth.C3_LENS, 1, 8, 5000, 1000, 0.001, [(0, -1)]
+    elif shape == "C4":
+        lens, kmin, kmax, w, inc, nfrac, slices = synth.C4_LENS, 1, 8, 2000, 500, 0.07, [(0, -1)]
+    else:
+        lens = [n for r in range(8) for n in synth.c5_shard_lens(8, r)]
+        kmin, kmax, w, inc, nfrac = 1, 8, 5000, 1000, 0.07
+        slices = [(0, 20000), (1_600_000, 1_620_000), (3_260_000, 3_280_000)]
+    with make_engine(kmin, kmax) as e:
+        e.synth(lens, seed={"C2": 2, "C3": 3, "C4": 4, "C5": 5}[shape], island_frac=0.02, n_frac=nfrac, lower_frac=0.01)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        res = e.scan(w, inc, rip=True)
+        S = OC.Seqs([e.read_seq(q) for q in range(len(lens))])
+        osym, ometa = OC.genome_profile(S, kmin, kmax)
+        assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+        ig = OC.genome_ivom(osym, ometa, kmin, kmax)
+        checked = 0
+        for a, b in slices:
+            exp = OC.scan(S, ig, kmin, kmax, w, inc, rip=True, cand=(a, b))
+            sl = slice(a, None if b < 0 else b)
+            k = np.nonzero(res.kept[sl])[0] + a
+            assert len(k) == len(exp["kld"])
+            assert np.array_equal(res.seq_index[k], exp["seq"])
+            assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"])
+            assert np.array_equal(res.gc[k], exp["gc"])
+            for col in ("pi", "si", "cri"):
+                assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
+            assert not np.any(exp["status"] & OC.ROW_ZERO_DIV) and not np.any(res.zero_weight[k])
+            assert np.array_equal((res.status[k] & _ffi.ROW_NO_MAXMER) != 0, (exp["status"] & OC.ROW_NO_MAXMER) != 0)
+            assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
+            checked += len(k)
+        assert checked > 5000
