@@ -59,7 +59,7 @@ struct frisk_ctx {
 
     // profile
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
-    DevBuf<double> d_ig;
+    DevBuf<double> d_ig, d_logtab;
     int64_t total_len = 0, ex_max = 0, nn_total = 0;
     bool profile_final = false;
 
@@ -219,6 +219,18 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
     HIPC(c, c->d_sym.reserve(size_t(c->nprof)));
     HIPC(c, c->d_ig.reserve(size_t(1) << (2 * kmax)));
     HIPC(c, hipMemsetAsync(c->d_raw.p, 0, (size_t(c->nprof) + 4) * sizeof(int64_t), c->stream));
+    {   // range-reduction table of the scan kernel's logarithm (scan_kernel.h: log_tab_pos)
+        double tab[2 * FRISK_LOGTAB_N];
+        for (int i = 0; i < FRISK_LOGTAB_N; ++i) {
+            const double ci = 0.5 + (double(i) + 0.5) / (2.0 * FRISK_LOGTAB_N);
+            const double u = 1.0 / ci;
+            tab[2 * i] = u;
+            tab[2 * i + 1] = double(-logl((long double)u));      // -ln of the ROUNDED reciprocal: the identity stays exact
+        }
+        HIPC(c, c->d_logtab.reserve(2 * FRISK_LOGTAB_N));
+        HIPC(c, hipMemcpyAsync(c->d_logtab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
     HIPC(c, hipStreamSynchronize(c->stream));
     return FRISK_OK;
 }
@@ -228,7 +240,7 @@ void frisk_destroy(frisk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_ascii.release(); c->d_codes.release(); c->d_inv.release(); c->d_low.release();
-    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_desc.release();
+    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
     c->o_kld.release(); c->o_gc.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
@@ -607,7 +619,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
 
     ScanParams P;
     P.codes = c->d_codes.p; P.inv = c->d_inv.p; P.low = c->d_low.p;
-    P.descs = c->d_desc.p; P.ig = c->d_ig.p;
+    P.descs = c->d_desc.p; P.ig = c->d_ig.p; P.log_tab = c->d_logtab.p;
     P.n_desc = c->n_seq + 1;
     P.kmin = c->kmin; P.kmax = c->kmax; P.w = w; P.inc = inc; P.flags = flags; P.c0 = c0; P.c1 = c1;
     P.orphan_cap = int32_t(c->plan_maxwin / 8 + 2);
@@ -619,7 +631,12 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
 
     const bool k8 = (c->kmax == 8);
-    const LdsLayout L = make_layout(c->kmin, c->kmax, P.orphan_cap);
+    // LDS budget: 160 KB per workgroup.  Long windows at K = 8 need a long orphan list; the shared prefix tables
+    // (12 KB, an optimisation only) make room for it.
+    P.lv = shared_level(c->kmin, c->kmax);
+    LdsLayout L = make_layout(c->kmin, c->kmax, P.orphan_cap, P.lv);
+    if (L.total > 160 * 1024 && P.lv) { P.lv = 0; L = make_layout(c->kmin, c->kmax, P.orphan_cap, 0); }
+    if (L.total > 160 * 1024) return fail(c, FRISK_E_ARG, "window too long for the 160 KB LDS of one workgroup");
     const int wg_per_cu = std::max(1, std::min(2, int(160 * 1024 / L.total)));
     int grid = int(std::min<int64_t>(n, int64_t(c->num_cu) * wg_per_cu));
     if (grid >= 8) grid &= ~7;

@@ -47,6 +47,7 @@ struct ScanParams {
     const uint32_t* low;
     const ScafDesc* descs;
     const double* ig;         // genome-side IVOM, 4^kmax entries (NaN = zero weight)
+    const double* log_tab;    // FRISK_LOGTAB_N pairs {1/c_i, ln c_i}: range reduction of log_tab_pos()
     int32_t n_desc;
     int32_t kmin, kmax;
     int32_t w, inc;
@@ -54,6 +55,7 @@ struct ScanParams {
     int64_t c0, c1;           // candidate range
     int32_t chunk;            // consecutive candidates handed to a workgroup at a time
     int32_t orphan_cap;       // capacity of the orphan list (entries)
+    int32_t lv;               // shared_level(), or 0 when the prefix tables do not fit beside a long window's orphan list
     int32_t nprof;            // profile length (debug dump stride)
     // outputs, indexed by (candidate - c0)
     int32_t* seq_index;
@@ -101,6 +103,7 @@ struct LdsLayout {
     uint32_t pre_i;     // f64[4^lv]: sum_{x<=lv} c_x^2 4^x/D_x of the lv-mer prefix
     uint32_t pre_w;     // u32[4^lv]: running weight sum after order lv
     uint32_t rtab;      // f64[16]: 4^x / ((S-(x-1))*2) per order x (window constants)
+    uint32_t logtab;    // f64[2*FRISK_LOGTAB_N]: {1/c_i, ln c_i}, written once per workgroup
     uint32_t misc;      // 2 x 16 u32 counters (double-buffered by window parity) + reduction scratch
     uint32_t total;
 };
@@ -109,13 +112,13 @@ struct LdsLayout {
 __host__ __device__ inline int shared_level(int kmin, int kmax) { return (kmin <= 5 && kmax >= 6) ? 5 : 0; }
 
 #define FRISK_MISC_SLOTS 16
+#define FRISK_LOGTAB_N 128
 #define FRISK_MISC_BYTES (2 * FRISK_MISC_SLOTS * 4 + 16 * 6 * 8)       // counters x2, scratch (16 waves x 3 x 128 bit)
 
-__host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap) {
+__host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap, int lv) {
     LdsLayout L;
     const bool k8 = (kmax == 8);
     const int ks = k8 ? 6 : kmax;
-    const int lv = shared_level(kmin, kmax);
     uint32_t o = 0;
     L.t8 = o;
     if (k8) o += FRISK_T8_BYTES;
@@ -131,6 +134,8 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
     if (lv) o += (1u << (2 * lv)) * 4;
     L.rtab = o;
     o += 16 * 8;
+    L.logtab = o;
+    o += FRISK_LOGTAB_N * 16;
     L.misc = o;
     o += FRISK_MISC_BYTES;
     L.total = (o + 15) / 16 * 16;
@@ -192,6 +197,28 @@ __device__ inline double log_pos(double x) {
     const double hfsq = 0.5 * f * f;
     const double dk = double(k);
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// ln(x) by table range reduction: x = m 2^k with m in [0.5, 1); the top 7 mantissa bits pick c_i = the midpoint of
+// m's 1/256-wide bin; tab[i] = {u_i = 1/c_i rounded to double, -ln(u_i)}; r = m u_i - 1 (one fma, |r| < 2^-8) and
+// ln x = k ln2 - ln u_i + log1p(r), log1p by its degree-7 Taylor polynomial (truncation < 2^-67).  ABSOLUTE error
+// ~1e-16 for the ratios scored here (|k| small) - what the sum T = sum Iw ln(Iw/Ig) needs - at 17 instructions
+// instead of log_pos()'s 42 (no division).
+__device__ inline double log_tab_pos(double x, const double2* tab) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const int k = __builtin_amdgcn_frexp_exp(x);
+    const double m = __builtin_amdgcn_frexp_mant(x);
+    const uint32_t i = (uint32_t(__double2hiint(m)) >> 13) & (FRISK_LOGTAB_N - 1);
+    const double2 e = tab[i];
+    const double r = __builtin_fma(m, e.x, -1.0);
+    double p = __builtin_fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = __builtin_fma(r, p, 1.0 / 5.0);
+    p = __builtin_fma(r, p, -1.0 / 4.0);
+    p = __builtin_fma(r, p, 1.0 / 3.0);
+    p = __builtin_fma(r, p, -0.5);
+    const double dk = double(k);
+    const double small = __builtin_fma(dk, ln2_lo, __builtin_fma(r * r, p, r));
+    return __builtin_fma(dk, ln2_hi, e.y) + small;
 }
 
 // ---- order-independent summation ---------------------------------------------------------------------
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
     const int lane = tid & 63;
     const int kmin = P.kmin;
     const int kmax = K8 ? 8 : P.kmax;                   // compile-time at K = 8: the order loops unroll
-    const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap);
+    const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap, P.lv);
     uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L.t8);
     uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
     uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L.small);
@@ -278,17 +305,19 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
     double* pre_i = reinterpret_cast<double*>(lds + L.pre_i);
     uint32_t* pre_w = reinterpret_cast<uint32_t*>(lds + L.pre_w);
     double* rtab = reinterpret_cast<double*>(lds + L.rtab);
+    double2* logtab = reinterpret_cast<double2*>(lds + L.logtab);
     using wsum_t = typename std::conditional<(ITS > 0), uint32_t, unsigned long long>::type;   // W < 2^32 for n <= 8192
     uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L.misc);
     double* scratch_base = reinterpret_cast<double*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
     const int ks = K8 ? 6 : kmax;                       // highest order kept in the small tables
-    const int lv = shared_level(kmin, kmax);            // recursion shared up to this order (0: not shared)
+    const int lv = P.lv;                                // recursion shared up to this order (0: not shared)
     const int kshift = 16 - 2 * kmax;
 
     // one-time clear of the histograms and counters
     if (K8) for (int i = tid; i < FRISK_T8_BYTES / 16; i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 2 * FRISK_MISC_SLOTS) misc_base[tid] = 0;
+    if (tid < FRISK_LOGTAB_N) logtab[tid] = reinterpret_cast<const double2*>(P.log_tab)[tid];
     __syncthreads();
 
     // XCD-aware work split: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
@@ -611,7 +640,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                     const double Iw = ratio * Ig;
                     const bool use = rep && !bad && (Iw == Iw);
                     // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
+#ifdef FRISK_LOG_FDLIBM
                     const double t = Iw * log_pos(ratio);
+#else
+                    const double t = Iw * log_tab_pos(ratio, logtab);
+#endif
                     exact_add(accw, use ? Iw : 0.0);
                     exact_add(accg, use ? Ig : 0.0);
                     exact_add(acct, use ? t : 0.0);

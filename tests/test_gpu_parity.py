@@ -395,3 +395,35 @@ def test_full_size_rows_against_c_oracle(shape):
             assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
             checked += len(k)
         assert checked > 5000
+
+
+@pytest.mark.parametrize("kmin,kmax,w,inc", [(1, 8, 40000, 15000), (1, 8, 65535, 30000), (3, 8, 30000, 29000),
+                                             (2, 7, 65535, 20000), (1, 4, 60000, 7000)])
+def test_long_windows_against_c_oracle(kmin, kmax, w, inc):
+    """Windows beyond the unrolled fast paths (generic kernel), up to the 65 535-base limit, with many invalid runs
+    (hence a long orphan list at K = 8, which displaces the shared prefix tables in LDS)."""
+    from oracle import frisk_oracle_c as OC
+    rng = np.random.default_rng(w + kmax)
+    seqs = []
+    for n in (250000, 70000, 66000):
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n, p=[0.35, 0.15, 0.2, 0.3])
+        for a in rng.integers(0, n - 40, size=n // 60):           # a short invalid run every ~60 bases
+            s[a:a + int(rng.integers(1, 4))] = ord("N")
+        s[1000:3000] |= 0x20                                       # a soft-masked stretch
+        seqs.append(s.tobytes())
+    with make_engine(kmin, kmax) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        rip = kmin <= 2
+        res = e.scan(w, inc, rip=rip)
+        osym, ometa = OC.genome_profile(seqs, kmin, kmax)
+        assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+        exp = OC.scan(seqs, OC.genome_ivom(osym, ometa, kmin, kmax), kmin, kmax, w, inc, rip=rip)
+        k = np.nonzero(res.kept)[0]
+        assert len(k) == len(exp["kld"]) and len(k) >= 3
+        assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"])
+        assert np.array_equal(res.gc[k], exp["gc"])
+        assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
+        with pytest.raises(Exception):
+            e.scan(65536, inc)
