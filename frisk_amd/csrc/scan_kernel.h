@@ -385,16 +385,38 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             const bool tally_by_ballot = (kmin != 1);
             {
                 uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
+                // ITS > 0: a lane owns ITS CONSECUTIVE positions, so one set of loads (3 + 2 + 2 words: ITS + 7 <= 23
+                // bases) serves all of them and the per-position fields come out by compile-time shifts.
+                const int j0 = (ITS > 0) ? tid * ITS : 0;
+                uint64_t acode = 0;                                          // bases j0 .. j0+31, first base in the top bits
+                uint32_t ainv = 0, alow = 0;                                 // validity / case bits of positions j0 .. j0+31
+                if (ITS > 0) {
+                    const int64_t gl = g0 + (j0 < n ? j0 : 0);               // clamped: loads are unconditional
+                    const int64_t wi = gl >> 4, mi = gl >> 5;
+                    const int shc = 32 - int(gl & 15) * 2, shm = 32 - int(gl & 31);
+                    const uint32_t w0 = P.codes[wi], w1 = P.codes[wi + 1], w2 = P.codes[wi + 2];
+                    const uint32_t hi = uint32_t(((uint64_t(w0) << 32) | w1) >> shc);
+                    const uint32_t lo = uint32_t(((uint64_t(w1) << 32) | w2) >> shc);
+                    acode = (uint64_t(hi) << 32) | lo;
+                    ainv = uint32_t(((uint64_t(P.inv[mi]) << 32) | P.inv[mi + 1]) >> shm);
+                    alow = uint32_t(((uint64_t(P.low[mi]) << 32) | P.low[mi + 1]) >> shm);
+                }
 #pragma unroll
                 for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
-                    if (ITS > 0 && it * NT >= n) { c16v[it] = 0; continue; }  // wave-uniform: past the window
-                    const int jj = tid + it * NT;
+                    const int jj = (ITS > 0) ? j0 + it : tid + it * NT;
                     const bool act = jj < n;
-                    const int64_t g = g0 + (act ? jj : 0);                   // clamped: loads are unconditional
-                    const uint32_t c16 = fetch_codes16(P.codes, g);
-                    const uint32_t inv8 = fetch_mask8(P.inv, g);
-                    const uint32_t low1 = fetch_mask1(P.low, g);
-                    if (ITS > 0) c16v[it] = c16;
+                    uint32_t c16, inv8, low1;
+                    if (ITS > 0) {
+                        c16 = uint32_t(acode >> (48 - 2 * it)) & 0xFFFFu;
+                        inv8 = (ainv >> (24 - it)) & 0xFFu;
+                        low1 = (alow >> (31 - it)) & 1u;
+                        c16v[it] = c16;
+                    } else {
+                        const int64_t g = g0 + (act ? jj : 0);               // clamped: loads are unconditional
+                        c16 = fetch_codes16(P.codes, g);
+                        inv8 = fetch_mask8(P.inv, g);
+                        low1 = fetch_mask1(P.low, g);
+                    }
                     const bool up = act && !((inv8 >> 7) | low1);
                     const uint32_t c2 = c16 >> 14;
                     int run = lead_clear8(inv8);                             // window words are upper-cased: L334-335
