@@ -154,8 +154,9 @@ struct WinTables {
     uint32_t o0, o1, o2, o3;     // the first four orphan 7-mers (0xFFFFFFFF = none), wave-uniform
     int kmin;
 
-    // count of the x-mer `c` in the current window (PLAIN: the window has at most four orphans)
-    template <bool PLAIN = false>
+    // count of the x-mer `c` in the current window.  ORPH = what the caller knows about the window's orphan list:
+    // 1: at most one entry (the usual case: the window's tail), 4: at most four, 0: anything
+    template <int ORPH = 0>
     __device__ inline uint32_t count(int x, uint32_t c) const {
         if (K8) {
             if (x == 8) return t8_16[c];
@@ -163,8 +164,9 @@ struct WinTables {
                 const uint2 q = *reinterpret_cast<const uint2*>(t8_16 + 4 * c);   // 4 children, 8-byte aligned
                 uint32_t s = (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16);
                 // orphans: a window has one (its tail) plus one per invalid run - almost always <= 4
-                s += (c == o0 ? 1u : 0u) + (c == o1 ? 1u : 0u) + (c == o2 ? 1u : 0u) + (c == o3 ? 1u : 0u);
-                if (!PLAIN) for (int o = 4; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
+                s += (c == o0 ? 1u : 0u);
+                if (ORPH != 1) s += (c == o1 ? 1u : 0u) + (c == o2 ? 1u : 0u) + (c == o3 ? 1u : 0u);
+                if (ORPH == 0) for (int o = 4; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
                 return s;
             }
         }
@@ -613,10 +615,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
 
             // ---- stage 4: every max-mer position of the lane: window-side IVOM (closed form), genome side from the
             // table, and the three sums  Sw = sum Iw,  Sg = sum Ig,  T = sum Iw ln(Iw/Ig)  over representatives
-            // plain_c: <= 4 orphans (no list loop in count(7));  lv_c: the shared prefix table is in use.  Both are
-            // window-uniform and resolved OUTSIDE the per-position loop so that its unrolled body is one basic block.
+            // plain_c: bound on the orphan list known to count(7) (1, 4, or 0 = none);  lv_c: the shared prefix table is in
+            // use.  Both are window-uniform and resolved OUTSIDE the per-position loop so that its unrolled body is one
+            // basic block.
             auto window_ivom = [&](uint32_t code, auto plain_c, auto lv_c, double& A_out) __attribute__((always_inline)) -> double {
-                constexpr bool PLAIN = decltype(plain_c)::value;
+                constexpr int PLAIN = decltype(plain_c)::value;
                 wsum_t W = 0;
                 double A = 0.0;
                 if constexpr (decltype(lv_c)::value) {
@@ -643,7 +646,13 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                 return double(W);
             };
             ExactSum accw = {0.0, 0.0}, accg = {0.0, 0.0}, acct = {0.0, 0.0};
-            bool zero_w = false;
+            // A lane that is not a representative must add exactly nothing.  Clearing only the HIGH word of its term
+            // leaves a subnormal (< 2^-1022), which both roundings of exact_add() turn into 0 - one select per term.
+            // Representatives are never screened: a max-mer without genome weight (Ig = NaN, L437) makes Sg NaN, and
+            // that is how the row's ZeroDivisionError is recognised below.
+            auto only_rep = [](bool rep, double x) -> double {
+                return __hiloint2double(rep ? __double2hiint(x) : 0, __double2loint(x));
+            };
             auto stage4 = [&](auto plain_c, auto lv_c) __attribute__((always_inline)) {
 #pragma unroll
                 for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
@@ -656,20 +665,17 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                     // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
                     double A;
                     const double Wd = window_ivom(code, plain_c, lv_c, A);
-                    const bool bad = (Ig != Ig);                            // zero weight in the genome (L437)
-                    zero_w |= rep && bad;
                     const double ratio = div_exact(A, Wd * Ig);
                     const double Iw = ratio * Ig;
-                    const bool use = rep && !bad && (Iw == Iw);
                     // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
 #ifdef FRISK_LOG_FDLIBM
                     const double t = Iw * log_pos(ratio);
 #else
                     const double t = Iw * log_tab_pos(ratio, logtab);
 #endif
-                    exact_add(accw, use ? Iw : 0.0);
-                    exact_add(accg, use ? Ig : 0.0);
-                    exact_add(acct, use ? t : 0.0);
+                    exact_add(accw, only_rep(rep, Iw));
+                    exact_add(accg, only_rep(rep, Ig));
+                    exact_add(acct, only_rep(rep, t));
 #ifndef FRISK_S4_GROUP
 #define FRISK_S4_GROUP 2
 #endif
@@ -678,14 +684,19 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                     if ((it % FRISK_S4_GROUP) == FRISK_S4_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            using orph1 = std::integral_constant<int, 1>;
+            using orph4 = std::integral_constant<int, 4>;
+            using orphN = std::integral_constant<int, 0>;
             if (lv) {
-                if (n_orph <= 4) stage4(std::true_type{}, std::true_type{}); else stage4(std::false_type{}, std::true_type{});
+                if (n_orph <= 1) stage4(orph1{}, std::true_type{});
+                else if (n_orph <= 4) stage4(orph4{}, std::true_type{});
+                else stage4(orphN{}, std::true_type{});
             } else {
-                if (n_orph <= 4) stage4(std::true_type{}, std::false_type{}); else stage4(std::false_type{}, std::false_type{});
+                if (n_orph <= 1) stage4(orph1{}, std::false_type{});
+                else if (n_orph <= 4) stage4(orph4{}, std::false_type{});
+                else stage4(orphN{}, std::false_type{});
             }
-            if (zero_w) atomicOr(&misc[M_FLAGS], ROW_ZERO_WEIGHT);
             block_sum3<NW>(accw, accg, acct, scratch_base, tid);
-            const uint32_t flags_lds = misc[M_FLAGS];
             zero_own_bins();                                // behind the barrier: nobody reads the max-mer table any more
             const double Sw = exact_value(accw), Sg = exact_value(accg), Tt = exact_value(acct);
             STOP_AFTER(4, Sw + Sg + Tt)
@@ -698,7 +709,8 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                 if (nvalid_top == 0) status |= ROW_NO_MAXMER;
                 // a zero divisor on the window side (L401-409) needs windowSpace in [kmin-1, kmax-1]
                 if (nvalid_top > 0 && S >= kmin - 1 && S <= kmax - 1) status |= ROW_ZERO_WEIGHT;
-                status |= ROW_KEPT | (flags_lds & ROW_ZERO_WEIGHT);
+                if (nvalid_top > 0 && Sg != Sg) status |= ROW_ZERO_WEIGHT;      // a max-mer without genome weight (L437)
+                status |= ROW_KEPT;
                 P.status[row] = status;
                 P.kld[row] = acc;
                 P.gc[row] = double(upG + upC) / double(S);              // L136

@@ -44,7 +44,7 @@ enum {
 
 /* per-row status bits written to `status` by frisk_scan */
 #define FRISK_ROW_KEPT        1u      /* window passed the < 30 % non-ACGT filter (L237-241)          */
-#define FRISK_ROW_ZERO_WEIGHT 2u      /* reference raises ZeroDivisionError for this window           */
+#define FRISK_ROW_ZERO_WEIGHT 2u      /* reference raises ZeroDivisionError for this window (kld = NaN) */
 #define FRISK_ROW_JUMPBACK    4u      /* end-of-scaffold "jumpback" window (0-based start, L230-243)  */
 #define FRISK_ROW_NO_MAXMER   8u      /* no valid max-mer: the reference's KLD is the int 0 (L465)    */
 
