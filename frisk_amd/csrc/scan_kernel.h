@@ -387,86 +387,137 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             const bool tally_by_ballot = (kmin != 1);
             {
                 uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
-                // ITS > 0: a lane owns ITS CONSECUTIVE positions, so one set of loads (3 + 2 + 2 words: ITS + 7 <= 23
-                // bases) serves all of them and the per-position fields come out by compile-time shifts.
-                const int j0 = (ITS > 0) ? tid * ITS : 0;
-                uint64_t acode = 0;                                          // bases j0 .. j0+31, first base in the top bits
-                uint32_t ainv = 0, alow = 0;                                 // validity / case bits of positions j0 .. j0+31
-                if (ITS > 0) {
+                // any position: ONE small-table update at the order of its longest valid word (<= 6 at K = 8), the
+                // max-mer update with the election, or the orphan list.  Returns whether the position holds a max-mer.
+                auto position_generic = [&](int it, int jj, uint32_t c16, uint32_t inv8) -> bool {
+                    int run = lead_clear8(inv8);                             // window words are upper-cased: L334-335
+                    const int rem = n - jj;
+                    run = run < rem ? run : rem;
+                    run = run < kmax ? run : kmax;
+                    bool is_top = false;
+                    if (K8) {
+                        const int rs = run < 6 ? run : 6;
+                        if (rs >= kmin) {
+                            const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (16 - 2 * rs));
+                            atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                        }
+                        if (run == 8) {
+                            const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
+                            is_top = true;
+                            if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                        } else if (run == 7 && kmin <= 7) {
+                            const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
+                            orph[slot] = uint16_t(c16 >> 2);
+                        }
+                    } else if (run >= kmin) {
+                        const uint32_t b = uint32_t(table_offset(kmin, run)) + (c16 >> (16 - 2 * run));
+                        if (run == kmax) {
+                            const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                            is_top = true;
+                            if (((old >> ((b & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                        } else {
+                            atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                        }
+                    }
+                    return is_top;
+                };
+                // composition tallies of one position by wave ballots (`sel`: the lanes whose base is counted)
+                auto tally = [&](bool sel, uint32_t c2) {
+                    cA += __popcll(__ballot(sel && c2 == 0));
+                    cT += __popcll(__ballot(sel && c2 == 1));
+                    cG += __popcll(__ballot(sel && c2 == 2));
+                    cC += __popcll(__ballot(sel && c2 == 3));
+                };
+                if constexpr (ITS > 0) {
+                    // A lane owns ITS CONSECUTIVE positions j0 .. j0+ITS-1: one set of loads (3 + 2 + 2 words; ITS + 7 <= 23
+                    // bases) serves all of them.  Bit 31-it of the lane masks below <-> position j0+it.
+                    const int j0 = tid * ITS;
                     const int64_t gl = g0 + (j0 < n ? j0 : 0);               // clamped: loads are unconditional
                     const int64_t wi = gl >> 4, mi = gl >> 5;
                     const int shc = 32 - int(gl & 15) * 2, shm = 32 - int(gl & 31);
                     const uint32_t w0 = P.codes[wi], w1 = P.codes[wi + 1], w2 = P.codes[wi + 2];
                     const uint32_t hi = uint32_t(((uint64_t(w0) << 32) | w1) >> shc);
                     const uint32_t lo = uint32_t(((uint64_t(w1) << 32) | w2) >> shc);
-                    acode = (uint64_t(hi) << 32) | lo;
-                    ainv = uint32_t(((uint64_t(P.inv[mi]) << 32) | P.inv[mi + 1]) >> shm);
-                    alow = uint32_t(((uint64_t(P.low[mi]) << 32) | P.low[mi + 1]) >> shm);
-                }
-#pragma unroll
-                for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
-                    const int jj = (ITS > 0) ? j0 + it : tid + it * NT;
-                    const bool act = jj < n;
-                    uint32_t c16, inv8, low1;
-                    if (ITS > 0) {
-                        c16 = uint32_t(acode >> (48 - 2 * it)) & 0xFFFFu;
-                        inv8 = (ainv >> (24 - it)) & 0xFFu;
-                        low1 = (alow >> (31 - it)) & 1u;
-                        c16v[it] = c16;
+                    const uint64_t acode = (uint64_t(hi) << 32) | lo;        // bases j0 .. j0+31, first base in the top bits
+                    const uint32_t ainv = uint32_t(((uint64_t(P.inv[mi]) << 32) | P.inv[mi + 1]) >> shm);
+                    const uint32_t alow = uint32_t(((uint64_t(P.low[mi]) << 32) | P.low[mi + 1]) >> shm);
+                    auto topbits = [](int k) -> uint32_t {                  // the k most significant bits (k clamped to 0..32)
+                        k = k < 0 ? 0 : (k > 32 ? 32 : k);
+                        return uint32_t(0xFFFFFFFF00000000ull >> k);
+                    };
+                    constexpr uint32_t MINE = uint32_t(0xFFFFFFFF00000000ull >> ITS);
+                    const int nleft = n - j0;                                // this lane's positions inside the window
+                    const uint32_t actm = topbits(nleft) & MINE;
+                    const uint32_t vld = ~ainv;
+                    uint32_t fullm = vld;                                    // kmax valid bases from here on ...
+                    if (K8) {
+                        fullm &= fullm << 1; fullm &= fullm << 2; fullm &= fullm << 4;
                     } else {
-                        const int64_t g = g0 + (act ? jj : 0);               // clamped: loads are unconditional
-                        c16 = fetch_codes16(P.codes, g);
-                        inv8 = fetch_mask8(P.inv, g);
-                        low1 = fetch_mask1(P.low, g);
+                        for (int i = 1; i < kmax; ++i) fullm &= vld << i;
                     }
-                    const bool up = act && !((inv8 >> 7) | low1);
-                    const uint32_t c2 = c16 >> 14;
-                    int run = lead_clear8(inv8);                             // window words are upper-cased: L334-335
-                    const int rem = n - jj;
-                    run = run < rem ? run : rem;
-                    run = run < kmax ? run : kmax;
-                    bool is_top = false;
-                    if (act) {
-                        if (K8) {
-                            const int rs = run < 6 ? run : 6;
-                            if (rs >= kmin) {
-                                const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (16 - 2 * rs));
-                                atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
-                            }
-                            if (run == 8) {
+                    fullm &= topbits(nleft - kmax + 1) & MINE;               // ... all of them inside the window
+                    const bool small_on = kmin <= 6;                         // K8: positions feed the order-6 table
+                    const uint32_t off_full = uint32_t(table_offset(kmin, K8 ? 6 : kmax));
+                    const int sh_full = K8 ? 4 : 16 - 2 * kmax;
+#pragma unroll
+                    for (int it = 0; it < ITS; ++it) {
+                        constexpr uint32_t TOP = 0x80000000u;
+                        const uint32_t bit = TOP >> it;
+                        const uint32_t c16 = uint32_t(acode >> (48 - 2 * it)) & 0xFFFFu;
+                        c16v[it] = c16;
+                        if (fullm & bit) {                                   // the usual case: a max-mer starts here
+                            if (K8) {
+                                if (small_on) {
+                                    const uint32_t b = off_full + (c16 >> 4);
+                                    atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                                }
                                 const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
-                                is_top = true;
                                 if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
-                            } else if (run == 7 && kmin <= 7) {
-                                const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
-                                orph[slot] = uint16_t(c16 >> 2);
-                            }
-                        } else if (run >= kmin) {
-                            const uint32_t b = uint32_t(table_offset(kmin, run)) + (c16 >> (16 - 2 * run));
-                            if (run == kmax) {
-                                const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
-                                is_top = true;
-                                if (((old >> ((b & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
                             } else {
-                                atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                                const uint32_t b = off_full + (c16 >> sh_full);
+                                const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                                if (((old >> ((b & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
                             }
+                        } else if (actm & bit) {                             // near an invalid base or the window's end
+                            position_generic(it, j0 + it, c16, (ainv >> (24 - it)) & 0xFFu);
                         }
                     }
+                    // wave total of the lanes' max-mer counts (<= ITS <= 16 each) from one ballot per bit - the compiler's
+                    // own reduction of a divergent atomic operand is a 64-step scalar loop
+                    const uint32_t ntop = __popc(fullm);
+#pragma unroll
+                    for (int b = 0; (1 << b) <= ITS; ++b) nvalid += uint32_t(__popcll(__ballot((ntop >> b) & 1u))) << b;
                     if (tally_by_ballot) {          // kmin > 1: no order-1 table to read the composition from
-                        cA += __popcll(__ballot(up && c2 == 0));
-                        cT += __popcll(__ballot(up && c2 == 1));
-                        cG += __popcll(__ballot(up && c2 == 2));
-                        cC += __popcll(__ballot(up && c2 == 3));
+                        const uint32_t upm = actm & vld & ~alow;
+#pragma unroll
+                        for (int it = 0; it < ITS; ++it)
+                            tally((upm >> (31 - it)) & 1u, uint32_t(acode >> (62 - 2 * it)) & 3u);
                     } else {                        // count only the soft-masked valid bases (rare): upper = C_1 - these
-                        const bool lowv = act && low1 && !(inv8 >> 7);
-                        if (__ballot(lowv)) {
-                            cA += __popcll(__ballot(lowv && c2 == 0));
-                            cT += __popcll(__ballot(lowv && c2 == 1));
-                            cG += __popcll(__ballot(lowv && c2 == 2));
-                            cC += __popcll(__ballot(lowv && c2 == 3));
+                        const uint32_t lowm = actm & vld & alow;
+                        if (__ballot(lowm != 0)) {
+#pragma unroll
+                            for (int it = 0; it < ITS; ++it)
+                                tally((lowm >> (31 - it)) & 1u, uint32_t(acode >> (62 - 2 * it)) & 3u);
                         }
                     }
-                    nvalid += __popcll(__ballot(is_top));
+                } else {
+                    for (int it = 0; it * NT < n; ++it) {
+                        const int jj = tid + it * NT;
+                        const bool act = jj < n;
+                        const int64_t g = g0 + (act ? jj : 0);               // clamped: loads are unconditional
+                        const uint32_t c16 = fetch_codes16(P.codes, g);
+                        const uint32_t inv8 = fetch_mask8(P.inv, g);
+                        const uint32_t low1 = fetch_mask1(P.low, g);
+                        const uint32_t c2 = c16 >> 14;
+                        const bool is_top = act && position_generic(it, jj, c16, inv8);
+                        if (tally_by_ballot) {
+                            tally(act && !((inv8 >> 7) | low1), c2);
+                        } else {
+                            const bool lowv = act && low1 && !(inv8 >> 7);
+                            if (__ballot(lowv)) tally(lowv, c2);
+                        }
+                        nvalid += __popcll(__ballot(is_top));
+                    }
                 }
                 if (lane == 0) {
                     if (cA) atomicAdd(&misc[M_UPA], cA);
