@@ -617,25 +617,44 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             T.kmin = kmin;
 
             // ---- stage 3: window constants r_x = 4^x / D_x, D_x = (S-(x-1))*2 (L401-409), and the shared prefix ---
-            if (tid >= 32 && tid < 32 + 9) {
-                const int x = tid - 32;                                     // orders 0..8 (0 unused)
-                rtab[x] = double(1u << (2 * x)) / double(int32_t((S - (x - 1)) * 2));
-            }
-            if (lv) __syncthreads();
-            // numerator / denominator of the closed form, orders kmin..lv, for every present lv-mer
+            // Lanes 0..8 of EVERY wave do the nine divisions; the other lanes read them by lane index (no barrier, no
+            // LDS round trip).  Wave 0 also stores them for the paths that index r_x at run time.
+            double r_lane = 0.0;
+            if (lane <= 8) r_lane = double(1u << (2 * lane)) / double(int32_t((S - (lane - 1)) * 2));
+            if (tid <= 8) rtab[tid] = r_lane;
+            auto r_of = [&](int x) -> double {                               // x: wave-uniform
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r_lane), x),
+                                        __builtin_amdgcn_readlane(__double2loint(r_lane), x));
+            };
+            // numerator / denominator of the closed form, orders kmin..lv, for every lv-mer (all orders of one entry are
+            // fetched before any is used; orders below kmin get weight 0 and a clamped address)
             if (lv) {
-                for (uint32_t c = tid; c < (1u << (2 * lv)); c += NT) {
-                    if (T.count(lv, c) == 0) continue;
-                    wsum_t W = 0;
+                constexpr int LV = 5;                                       // == shared_level() whenever it is not 0
+                double rx[LV + 1];
+                uint32_t ox[LV + 1], wm[LV + 1];
+#pragma unroll
+                for (int x = 1; x <= LV; ++x) {
+                    const bool on = x >= kmin;
+                    rx[x] = on ? r_of(x) : 0.0;
+                    ox[x] = on ? uint32_t(table_offset(kmin, x)) : 0u;
+                    wm[x] = on ? 0xFFFFFFFFu : 0u;
+                }
+#pragma unroll
+                for (int e = 0; e < (1 << (2 * LV)) / NT; ++e) {
+                    const uint32_t c = tid + e * NT;
+                    uint32_t cx[LV + 1];
+#pragma unroll
+                    for (int x = 1; x <= LV; ++x) cx[x] = small16[ox[x] + (c >> (2 * (LV - x)))];
+                    uint32_t W = 0;
                     double A = 0.0;
-                    for (int x = kmin; x <= lv; ++x) {
-                        const uint32_t cx = T.count(x, c >> (2 * (lv - x)));
-                        const double cd = double(cx);
-                        W += wsum_t(cx) << (2 * x);                         // count * 4**x (L399-408)
-                        A = __builtin_fma(cd * cd, rtab[x], A);             // w_x * p_x = c^2 4^x / D_x
+#pragma unroll
+                    for (int x = 1; x <= LV; ++x) {
+                        const double cd = double(cx[x]);
+                        W += (cx[x] & wm[x]) << (2 * x);                    // count * 4**x (L399-408)
+                        A = __builtin_fma(cd * cd, rx[x], A);               // w_x * p_x = c^2 4^x / D_x
                     }
                     pre_i[c] = A;
-                    pre_w[c] = uint32_t(W);         // < 65536 * 4^6
+                    pre_w[c] = W;                   // < 65536 * 4^6
                 }
             }
             __syncthreads();
@@ -669,6 +688,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             // plain_c: bound on the orphan list known to count(7) (1, 4, or 0 = none);  lv_c: the shared prefix table is in
             // use.  Both are window-uniform and resolved OUTSIDE the per-position loop so that its unrolled body is one
             // basic block.
+            double r_hi[3];                                                 // r_6, r_7, r_8: the orders above the shared prefix
+#pragma unroll
+            for (int x = 6; x <= 8; ++x) r_hi[x - 6] = r_of(x);
             auto window_ivom = [&](uint32_t code, auto plain_c, auto lv_c, double& A_out) __attribute__((always_inline)) -> double {
                 constexpr int PLAIN = decltype(plain_c)::value;
                 wsum_t W = 0;
@@ -683,7 +705,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                         const uint32_t cx = T.template count<PLAIN>(x, code >> (2 * (kmax - x)));
                         const double cd = double(cx);
                         W += wsum_t(cx) << (2 * x);
-                        A = __builtin_fma(cd * cd, rtab[x], A);
+                        A = __builtin_fma(cd * cd, K8 ? r_hi[x - LV - 1] : rtab[x], A);    // K8: x is compile-time
                     }
                 } else {
                     for (int x = kmin; x <= kmax; ++x) {
