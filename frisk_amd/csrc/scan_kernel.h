@@ -529,6 +529,23 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             }
             __syncthreads();
             if (tid < FRISK_MISC_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
+            auto code16_at = [&](int it) -> uint32_t {
+                if (ITS > 0) return c16v[it];
+                return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT);
+            };
+            auto zero_own_bins = [&]() {        // representatives zero their max-mer bin (K8; the small tables are
+                if (K8) {                       // cleared wholesale)
+#pragma unroll
+                    for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it)
+                        if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code16_at(it)] = 0;
+                }
+            };
+            auto clear_small = [&]() {
+                for (uint32_t i = tid; i < L.small_bytes / 16; i += NT)
+                    reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
+            };
+            auto cleanup = [&]() { zero_own_bins(); clear_small(); };
+            STOP_AFTER(0, misc[M_NVALID])
 
             // ---- stage 2: marginalise the small tables: C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b] --------------
             auto marg_level = [&](int x, int first, int step) {
@@ -572,22 +589,6 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                 P.start[row] = rep_start;
                 P.stop[row] = rep_stop;
             }
-            auto code16_at = [&](int it) -> uint32_t {
-                if (ITS > 0) return c16v[it];
-                return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT);
-            };
-            auto zero_own_bins = [&]() {        // representatives zero their max-mer bin (K8; the small tables are
-                if (K8) {                       // cleared wholesale)
-#pragma unroll
-                    for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it)
-                        if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code16_at(it)] = 0;
-                }
-            };
-            auto clear_small = [&]() {
-                for (uint32_t i = tid; i < L.small_bytes / 16; i += NT)
-                    reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
-            };
-            auto cleanup = [&]() { zero_own_bins(); clear_small(); };
             if (!keep) {
                 cleanup();
                 if (tid == 0) {
