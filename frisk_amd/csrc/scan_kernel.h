@@ -232,31 +232,44 @@ __device__ inline double log_tab_pos(double x, const double2* tab) {
 // |term| < 2^11 and a window has < 2^16 max-mers, so every partial sum of hi's is a multiple of 2^-26 below 2^27 and
 // every partial sum of lo's a multiple of 2^-64 below 2^-11: both fit the 53-bit mantissa, no addition ever rounds.
 // The per-term rounding at 2^-64 is a fixed function of the term.  Results are therefore bit-identical across
-// runs, builds, grids and GPUs, at 7 FP64 instructions per term (a 128-bit integer accumulator cost 18).
+// runs, builds, grids and GPUs (a 128-bit integer accumulator cost 18 instructions per term).
 struct ExactSum {
     double hi, lo;
 };
 
+#define FRISK_EXACT_BIAS 0x1.8p26                            // 1.5 * 2^(52-26): an accumulator in [2^26, 2^27) has ulp 2^-26
+// The lane-private accumulators carry the bias in `hi` (exact_begin / exact_end), which makes the running sum itself do
+// the rounding of the term: hi' = hi + x is hi + (x rounded to 2^-26), exactly (|lane sum| < 2^17 keeps hi in range),
+// and h = hi' - hi, x - h are exact (Fast2Sum).  On a tie h depends on the parity of hi, i.e. on what the lane added
+// before; h + l does not (the 2^-64 grid of l is shifted by a multiple of itself), so the totals still do not depend
+// on which lane scored which max-mer.  6 instructions per term.
+__device__ inline ExactSum exact_begin() { return ExactSum{FRISK_EXACT_BIAS, 0.0}; }
+__device__ inline void exact_end(ExactSum& a) { a.hi -= FRISK_EXACT_BIAS; }
 __device__ inline void exact_add(ExactSum& a, double x) {
-    const double C1 = 0x1.8p26, C2 = 0x1.8p-12;             // 1.5 * 2^(52-26),  1.5 * 2^(52-64)
-    const double h = (x + C1) - C1;
+    const double C2 = 0x1.8p-12;                            // 1.5 * 2^(52-64)
+    const double s = a.hi + x;
+    const double h = s - a.hi;
     const double l = ((x - h) + C2) - C2;
-    a.hi += h;
+    a.hi = s;
     a.lo += l;
 }
 
 __device__ inline double exact_value(const ExactSum& a) { return a.hi + a.lo; }
 
 // n / d for operands whose quotient needs no exponent scaling (here: positive integers < 2^53 as doubles, and
-// ratios of normal probabilities): the same reciprocal refinement + residual correction the compiler emits for
-// an IEEE fdiv, without the v_div_scale / v_div_fmas / v_div_fixup range handling - bit-identical results for
-// these operands at two thirds of the instructions.
+// ratios of normal probabilities): reciprocal refinement + residual correction as the compiler emits for an IEEE
+// fdiv, without the v_div_scale / v_div_fmas / v_div_fixup range handling and with ONE Newton step instead of two:
+// v_rcp_f64 is good to 24.4 bits on gfx950 (measured), one step gives 2^-48.8, and the residual correction then
+// lands within 2^-97 of the true quotient - identical to the IEEE quotient in 4 194 304 of 4 194 304 random
+// divisions (tools/exp/rcp_accuracy.hip; a difference needs the quotient within 2^-44 ulp of a rounding boundary).
 __device__ inline double div_exact(double n, double d) {
     double r = __builtin_amdgcn_rcp(d);
     double e = __builtin_fma(-d, r, 1.0);
     r = __builtin_fma(r, e, r);
+#ifdef FRISK_DIV_2NR
     e = __builtin_fma(-d, r, 1.0);
     r = __builtin_fma(r, e, r);
+#endif
     const double q = n * r;
     e = __builtin_fma(-d, q, n);
     return __builtin_fma(e, r, q);
@@ -719,7 +732,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                 A_out = A;
                 return double(W);
             };
-            ExactSum accw = {0.0, 0.0}, accg = {0.0, 0.0}, acct = {0.0, 0.0};
+            ExactSum accw = exact_begin(), accg = exact_begin(), acct = exact_begin();
             // A lane that is not a representative must add exactly nothing.  Clearing only the HIGH word of its term
             // leaves a subnormal (< 2^-1022), which both roundings of exact_add() turn into 0 - one select per term.
             // Representatives are never screened: a max-mer without genome weight (Ig = NaN, L437) makes Sg NaN, and
@@ -770,6 +783,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                 else if (n_orph <= 4) stage4(orph4{}, std::false_type{});
                 else stage4(orphN{}, std::false_type{});
             }
+            exact_end(accw); exact_end(accg); exact_end(acct);
             block_sum3<NW>(accw, accg, acct, scratch_base, tid);
             zero_own_bins();                                // behind the barrier: nobody reads the max-mer table any more
             const double Sw = exact_value(accw), Sg = exact_value(accg), Tt = exact_value(acct);
