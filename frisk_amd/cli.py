@@ -252,13 +252,11 @@ def main(argv=None):
 
 
 def _sharded(hp, args, querySeq, rip):
-    """N ranks, one job: frisk_amd.distributed.run_sharded; returns rows (rank 0) in table form."""
-    from .distributed import run_sharded
-    from .fasta import readFasta
-    names, seqs = readFasta(args.hostSeq)
-    query = readFasta(querySeq) if querySeq != args.hostSeq else None
-    rows = run_sharded(hp.engine, names, seqs, args.windowlen, args.increment, mask_host=args.maskHost, rip=rip,
-                       scaffolds_all=args.scaffoldsAll, query=query)
+    """N ranks, one job: frisk_amd.distributed.run_sharded_files (every rank reads the FASTA natively and takes an
+    equal share of the positions and of the candidate windows); returns rows (rank 0) in table form."""
+    from .distributed import run_sharded_files
+    rows = run_sharded_files(hp.engine, args.hostSeq, args.windowlen, args.increment, mask_host=args.maskHost, rip=rip,
+                             scaffolds_all=args.scaffoldsAll, query_path=querySeq)
     if rows is None:
         return None
     from . import _ffi

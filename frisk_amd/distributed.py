@@ -102,6 +102,11 @@ def run_sharded(engine, names, seqs, w, inc, mask_host=False, rip=False, scaffol
         seq_global = res.seq_index.astype(np.int64)
         cand_key = np.arange(c0, c1, dtype=np.int64)
 
+    return _gather_rows(dist, group, rank, world, res, seq_global, cand_key, qnames, rip)
+
+
+def _gather_rows(dist, group, rank, world, res, seq_global, cand_key, qnames, rip):
+    """Rows of all ranks on rank 0, in the reference's output order (scaffold order, then candidate order)."""
     keep = res.kept
     local = {"seq": seq_global[keep], "key": cand_key[keep], "start": res.start[keep], "stop": res.stop[keep],
              "status": res.status[keep], "kld": res.kld[keep], "gc": res.gc[keep]}
@@ -125,3 +130,29 @@ def run_sharded(engine, names, seqs, w, inc, mask_host=False, rip=False, scaffol
             row += (float(merged["pi"][r]), float(merged["si"][r]), float(merged["cri"][r]))
         rows.append(row)
     return rows
+
+
+def run_sharded_files(engine, host_path, w, inc, mask_host=False, rip=False, scaffolds_all=False, group=None,
+                      query_path=None):
+    """The same job straight from FASTA files: REPLICATED data, sharded work.  Every rank reads the whole file with
+    the native reader (`Engine.load_fasta`; a 3 Gb assembly is < 1.3 GB packed, nothing beside 288 GB of HBM), counts
+    the k-mers that start in its contiguous range of padded positions, joins the one all-reduce, and scans its
+    contiguous range of candidate windows - balanced whatever the scaffold lengths, and no sequence ever exists as
+    a Python string.  Rows as `run_sharded`."""
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    names = engine.load_fasta(host_path)
+    engine.profile_reset()
+    p0, p1 = split_range(engine.padded_len, rank, world)
+    engine.profile_add(mask_host=mask_host, pos_begin=p0, pos_end=p1)
+    engine.profile_allreduce(group)
+    engine.profile_finalize()
+    qnames = names
+    if query_path is not None and query_path != host_path:
+        qnames = engine.load_fasta(query_path)
+    total = engine.scan_plan(w, inc, scaffolds_all)
+    c0, c1 = split_range(total, rank, world)
+    res = engine.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all, c0=c0, c1=c1)
+    return _gather_rows(dist, group, rank, world, res, res.seq_index.astype(np.int64),
+                        np.arange(c0, c1, dtype=np.int64), qnames, rip)

@@ -24,6 +24,12 @@ class FakeEngine:
             pos += e.n + 1
         self._padded = max(32, (pos + 31) // 32 * 32)
 
+    def load_fasta(self, path):
+        from frisk_amd.fasta import readFasta
+        names, seqs = readFasta(path)
+        self.load(seqs)
+        return names
+
     @property
     def padded_len(self):
         return self._padded

@@ -28,13 +28,18 @@ def _job(mode):
 def _run(rank, world, port, mode, out_path):
     import torch.distributed as dist
     from fake_engine import FakeEngine
-    from frisk_amd.distributed import run_sharded
+    from frisk_amd.distributed import run_sharded, run_sharded_files
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    recs, kw = _job(mode)
-    eng = FakeEngine(kw["kmin"], kw["kmax"])
-    rows = run_sharded(eng, [n for n, _ in recs], [s for _, s in recs], kw["w"], kw["inc"], rip=kw["rip"],
-                       scaffolds_all=kw["scaffolds_all"], mode=mode)
+    if mode == "files":         # the CLI's mode: replicated data from FASTA files, host != query
+        eng = FakeEngine(1, 4)
+        rows = run_sharded_files(eng, os.path.join(INPUTS, "host.fa"), 400, 150, rip=True, scaffolds_all=True,
+                                 query_path=os.path.join(INPUTS, "query.fa"))
+    else:
+        recs, kw = _job(mode)
+        eng = FakeEngine(kw["kmin"], kw["kmax"])
+        rows = run_sharded(eng, [n for n, _ in recs], [s for _, s in recs], kw["w"], kw["inc"], rip=kw["rip"],
+                           scaffolds_all=kw["scaffolds_all"], mode=mode)
     sym, tl, ex, nn = eng.profile_get()
     if rank == 0:
         np.save(out_path, np.array([rows, sym, (tl, ex, nn)], dtype=object), allow_pickle=True)
@@ -43,7 +48,7 @@ def _run(rank, world, port, mode, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["scaffold", "range"])
+@pytest.mark.parametrize("mode", ["scaffold", "range", "files"])
 def test_two_ranks_equal_one(tmp_path, mode):
     single = str(tmp_path / "single.npy")
     double = str(tmp_path / "double.npy")
