@@ -154,6 +154,16 @@ struct WinTables {
     uint32_t o0, o1, o2, o3;     // the first four orphan 7-mers (0xFFFFFFFF = none), wave-uniform
     int kmin;
 
+    // occurrences of the 7-mer `c` in the orphan list: a window has one orphan (its tail) plus one per invalid run -
+    // almost always <= 4
+    template <int ORPH = 0>
+    __device__ inline uint32_t orphans(uint32_t c) const {
+        uint32_t s = (c == o0 ? 1u : 0u);
+        if (ORPH != 1) s += (c == o1 ? 1u : 0u) + (c == o2 ? 1u : 0u) + (c == o3 ? 1u : 0u);
+        if (ORPH == 0) for (int o = 4; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
+        return s;
+    }
+
     // count of the x-mer `c` in the current window.  ORPH = what the caller knows about the window's orphan list:
     // 1: at most one entry (the usual case: the window's tail), 4: at most four, 0: anything
     template <int ORPH = 0>
@@ -163,11 +173,7 @@ struct WinTables {
             if (x == 7) {
                 const uint2 q = *reinterpret_cast<const uint2*>(t8_16 + 4 * c);   // 4 children, 8-byte aligned
                 uint32_t s = (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16);
-                // orphans: a window has one (its tail) plus one per invalid run - almost always <= 4
-                s += (c == o0 ? 1u : 0u);
-                if (ORPH != 1) s += (c == o1 ? 1u : 0u) + (c == o2 ? 1u : 0u) + (c == o3 ? 1u : 0u);
-                if (ORPH == 0) for (int o = 4; o < n_orph; ++o) s += (orph[o] == c) ? 1u : 0u;
-                return s;
+                return s + orphans<ORPH>(c);
             }
         }
         return small16[table_offset(kmin, x) + c];
@@ -586,17 +592,20 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                     __syncthreads();
                 }
             }
-            uint32_t upA = misc[M_UPA], upT = misc[M_UPT], upG = misc[M_UPG], upC = misc[M_UPC];
+            // window-uniform values read back from LDS are moved to scalar registers: they stay live to the end of the
+            // window and must not cost a vector register (nor depend on which lanes a later loop leaves active)
+            auto uni = [](uint32_t v) -> uint32_t { return __builtin_amdgcn_readfirstlane(v); };
+            uint32_t upA = uni(misc[M_UPA]), upT = uni(misc[M_UPT]), upG = uni(misc[M_UPG]), upC = uni(misc[M_UPC]);
             if (!tally_by_ballot) {             // kmin == 1: the order-1 table starts the small tables
-                upA = small16[0] - upA; upT = small16[1] - upT; upG = small16[2] - upG; upC = small16[3] - upC;
+                upA = uni(small16[0]) - upA; upT = uni(small16[1]) - upT; upG = uni(small16[2]) - upG; upC = uni(small16[3]) - upC;
             }
             const int64_t S = int64_t(upA) + upT + upG + upC;       // windowSpace (L380)
             const int64_t nn = n - S;                               // nnTotal of the window
             // N filter (L237-241 / L213): dropped when nn >= 0.3 * len, evaluated in double like CPython
             const bool keep = !(double(nn) >= 0.3 * double(n));
             uint32_t status = (jump ? ROW_JUMPBACK : 0u);
-            const uint32_t nvalid_top = misc[M_NVALID];
-            const int n_orph = K8 ? int(misc[M_NORPH]) : 0;
+            const uint32_t nvalid_top = uni(misc[M_NVALID]);
+            const int n_orph = K8 ? int(uni(misc[M_NORPH])) : 0;
             if (tid == 0) {
                 P.seq_index[row] = dsi;
                 P.start[row] = rep_start;
@@ -686,15 +695,25 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                 P.dbg_meta[row * 3 + 1] = (n >= kmax ? n - kmax + 1 : 0) - int64_t(nvalid_top); // exMax (L344-345)
                 P.dbg_meta[row * 3 + 2] = nn;                                                  // nnTotal
             }
-            // RIP indices from the window's dinucleotide counts (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3
-            double pi = 0, si = 0, cri = 0;
-            if ((P.flags & 1u) && tid == 0) {
-                const double qnan = __longlong_as_double(0x7FF8000000000000LL);
-                const uint32_t AT = T.count(2, 1), TA = T.count(2, 4), TG = T.count(2, 6), GT = T.count(2, 9),
-                               CA = T.count(2, 12), AC = T.count(2, 3);
-                pi = AT > 0 ? double(TA) / double(AT) : qnan;
-                si = (AC + GT) > 0 ? double(CA + TG) / double(AC + GT) : qnan;
-                cri = (pi == 0.0 || si == 0.0) ? qnan : pi - si;        // "if PI and SI" (L491): 0.0 is falsy
+            // Everything about the row that is already known is written NOW (composition, RIP indices, status bits):
+            // nothing but the three sums has to stay live across stage 4.
+            if (nvalid_top == 0) status |= ROW_NO_MAXMER;
+            // a zero divisor on the window side (L401-409) needs windowSpace in [kmin-1, kmax-1]
+            if (nvalid_top > 0 && S >= kmin - 1 && S <= kmax - 1) status |= ROW_ZERO_WEIGHT;
+            status |= ROW_KEPT;
+            if (tid == 0) {
+                P.gc[row] = double(upG + upC) / double(S);                  // L136
+                // RIP indices from the window's dinucleotide counts (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3
+                if (P.flags & 1u) {
+                    const double qnan = __longlong_as_double(0x7FF8000000000000LL);
+                    const uint32_t AT = T.count(2, 1), TA = T.count(2, 4), TG = T.count(2, 6), GT = T.count(2, 9),
+                                   CA = T.count(2, 12), AC = T.count(2, 3);
+                    const double pi = AT > 0 ? double(TA) / double(AT) : qnan;
+                    const double si = (AC + GT) > 0 ? double(CA + TG) / double(AC + GT) : qnan;
+                    P.pi[row] = pi;
+                    P.si[row] = si;
+                    P.cri[row] = (pi == 0.0 || si == 0.0) ? qnan : pi - si; // "if PI and SI" (L491): 0.0 is falsy
+                }
             }
 
             // ---- stage 4: every max-mer position of the lane: window-side IVOM (closed form), genome side from the
@@ -714,6 +733,22 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
                     const uint32_t pc = code >> (2 * (kmax - LV));
                     W = pre_w[pc];
                     A = pre_i[pc];
+                    if constexpr (K8) {
+                        // orders 6, 7, 8 with ONE read of the max-mer table: the max-mer's own count is one of the four
+                        // children summed for its 7-mer prefix
+                        const uint32_t c6 = T.template count<PLAIN>(6, code >> 4);
+                        const uint32_t q7 = code >> 2;
+                        const uint2 ch = *reinterpret_cast<const uint2*>(T.t8_16 + 4 * q7);
+                        const uint64_t both = (uint64_t(ch.y) << 32) | ch.x;
+                        const uint32_t c8 = uint32_t(both >> ((code & 3u) * 16)) & 0xFFFFu;
+                        uint32_t c7 = (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
+                        c7 += T.template orphans<PLAIN>(q7);
+                        const double d6 = double(c6), d7 = double(c7), d8 = double(c8);
+                        W += (wsum_t(c6) << 12) + (wsum_t(c7) << 14) + (wsum_t(c8) << 16);
+                        A = __builtin_fma(d6 * d6, r_hi[0], A);
+                        A = __builtin_fma(d7 * d7, r_hi[1], A);
+                        A = __builtin_fma(d8 * d8, r_hi[2], A);
+                    } else
 #pragma unroll
                     for (int x = LV + 1; x <= kmax; ++x) {
                         const uint32_t cx = T.template count<PLAIN>(x, code >> (2 * (kmax - x)));
@@ -794,15 +829,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
 
             clear_small();                                  // all reads of the small tables are behind the barrier
             if (tid == 0) {
-                if (nvalid_top == 0) status |= ROW_NO_MAXMER;
-                // a zero divisor on the window side (L401-409) needs windowSpace in [kmin-1, kmax-1]
-                if (nvalid_top > 0 && S >= kmin - 1 && S <= kmax - 1) status |= ROW_ZERO_WEIGHT;
                 if (nvalid_top > 0 && Sg != Sg) status |= ROW_ZERO_WEIGHT;      // a max-mer without genome weight (L437)
-                status |= ROW_KEPT;
                 P.status[row] = status;
                 P.kld[row] = acc;
-                P.gc[row] = double(upG + upC) / double(S);              // L136
-                if (P.flags & 1u) { P.pi[row] = pi; P.si[row] = si; P.cri[row] = cri; }
             }
             __syncthreads();
         }

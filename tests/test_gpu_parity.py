@@ -397,9 +397,11 @@ def test_full_size_rows_against_c_oracle(shape):
         assert checked > 5000
 
 
+@pytest.mark.parametrize("want_rip", [False, True])
 @pytest.mark.parametrize("kmin,kmax,w,inc", [(1, 8, 40000, 15000), (1, 8, 65535, 30000), (3, 8, 30000, 29000),
-                                             (2, 7, 65535, 20000), (1, 4, 60000, 7000)])
-def test_long_windows_against_c_oracle(kmin, kmax, w, inc):
+                                             (2, 7, 65535, 20000), (1, 4, 60000, 7000), (2, 8, 9000, 4000),
+                                             (4, 8, 20000, 9000), (1, 6, 12000, 5000), (5, 5, 10000, 3000)])
+def test_long_windows_against_c_oracle(kmin, kmax, w, inc, want_rip):
     """Windows beyond the unrolled fast paths (generic kernel), up to the 65 535-base limit, with many invalid runs
     (hence a long orphan list at K = 8, which displaces the shared prefix tables in LDS)."""
     from oracle import frisk_oracle_c as OC
@@ -415,7 +417,9 @@ def test_long_windows_against_c_oracle(kmin, kmax, w, inc):
         e.load(seqs)
         e.profile_reset(); e.profile_add(); e.profile_finalize()
         sym, tl, ex, nn = e.profile_get()
-        rip = kmin <= 2
+        rip = want_rip and kmin <= 2
+        if want_rip and not rip:
+            pytest.skip("RIP needs kmin <= 2")
         res = e.scan(w, inc, rip=rip)
         osym, ometa = OC.genome_profile(seqs, kmin, kmax)
         assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
@@ -424,6 +428,10 @@ def test_long_windows_against_c_oracle(kmin, kmax, w, inc):
         assert len(k) == len(exp["kld"]) and len(k) >= 3
         assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"])
         assert np.array_equal(res.gc[k], exp["gc"])
+        assert np.array_equal(res.status[k] & 0xB, (exp["status"] & 0xA) | 1)       # KEPT | ZERO_WEIGHT | NO_MAXMER
+        if rip:
+            for col in ("pi", "si", "cri"):
+                assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
         assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
         with pytest.raises(Exception):
             e.scan(65536, inc)
