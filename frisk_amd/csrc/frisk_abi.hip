@@ -444,9 +444,10 @@ int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
     const int halves = (c->kmax == 8) ? 2 : 1;
     const size_t lds = (size_t(1) << (2 * c->kmax)) / size_t(halves) * 4;
     const int64_t span = p1 - p0;
+    const int64_t nwords = span > 0 ? ((p1 + 31) >> 5) - (p0 >> 5) : 0;     // a lane takes one 32-position bitmap word
     int64_t nchunks = std::min<int64_t>(std::max<int64_t>(1, span / 65536), int64_t(c->num_cu) * (halves == 2 ? 1 : 2));
-    const int64_t chunk_len = (span + nchunks - 1) / std::max<int64_t>(nchunks, 1);
-    nchunks = chunk_len > 0 ? (span + chunk_len - 1) / chunk_len : 0;
+    const int64_t chunk_len = (nwords + nchunks - 1) / std::max<int64_t>(nchunks, 1);   // in words
+    nchunks = chunk_len > 0 ? (nwords + chunk_len - 1) / chunk_len : 0;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     if (span > 0) {
         auto raw = reinterpret_cast<unsigned long long*>(c->d_raw.p);

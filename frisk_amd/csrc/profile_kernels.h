@@ -76,6 +76,9 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict_
 // workgroup makes its pass over its chunk for ONE half (grid = chunks x halves; the sequence is 0.5 B/base,
 // reading it twice is free).  Orders below K (positions next to an invalid base or a scaffold end) go straight
 // to global atomics, as do the three scalars (one atomic per wave).  Half 0 alone counts those.
+// A lane owns one 32-position WORD of the bitmaps (7 loads: two words of each bitmap, three of the codes); the
+// run flags of its 32 positions come from whole-word shifts, the codes from constant shifts, so a position costs
+// about ten instructions instead of its own three unaligned fetches.
 // ------------------------------------------------------------------------------------------------
 #define FRISK_PROF_NT 1024
 
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(FRISK_PROF_NT) void profile_add_kernel(const uint32
                                                                      const uint32_t* __restrict__ inv,
                                                                      const uint32_t* __restrict__ low, int64_t p0, int64_t p1,
                                                                      int kmin, int kmax, int mask_host, int nprof,
-                                                                     int halves, int64_t chunk_len,
+                                                                     int halves, int64_t chunk_words,
                                                                      unsigned long long* __restrict__ raw) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const int half = int(blockIdx.x) % halves;
@@ -93,28 +96,55 @@ __global__ __launch_bounds__(FRISK_PROF_NT) void profile_add_kernel(const uint32
     if (nbins < 4) for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     unsigned long long tot = 0, kpos = 0, nn = 0;
-    const int64_t cb = p0 + chunk * chunk_len;
-    int64_t ce = cb + chunk_len;
-    if (ce > p1) ce = p1;
+    const int64_t w_first = p0 >> 5, w_end = (p1 + 31) >> 5;               // bitmap words that hold [p0, p1)
+    const int64_t wb = w_first + chunk * chunk_words;
+    int64_t we = wb + chunk_words;
+    if (we > w_end) we = w_end;
     const int64_t offK = table_offset(kmin, kmax);
-    for (int64_t p = cb + threadIdx.x; p < ce; p += blockDim.x) {
-        const uint32_t inv8 = fetch_mask8(inv, p), low8 = fetch_mask8(low, p);
-        const uint32_t eff = inv8 | (mask_host ? low8 : 0u);
-        int run = lead_clear8(eff);
-        run = run < kmax ? run : kmax;
-        if (run == kmax) {
-            const uint32_t code = fetch_codes16(codes, p) >> (16 - 2 * kmax);
-            if (int(code / nbins) == half) atomicAdd(&hist[code & (nbins - 1)], 1u);
-        } else if (half == 0 && run >= kmin) {
-            const uint32_t code = fetch_codes16(codes, p) >> (16 - 2 * run);
-            atomicAdd(&raw[table_offset(kmin, run) + code], 1ull);
+    const int shK = 16 - 2 * kmax;
+    const uint32_t halfbit = (halves == 2) ? nbins : 0u;                    // the leading bit of the code picks the half
+    auto topbits = [](int64_t k) -> uint32_t {                             // the k most significant bits (k clamped to 0..32)
+        k = k < 0 ? 0 : (k > 32 ? 32 : k);
+        return uint32_t(0xFFFFFFFF00000000ull >> k);
+    };
+    for (int64_t wq = wb + threadIdx.x; wq < we; wq += blockDim.x) {
+        const int64_t base = wq << 5;                                       // position of bit 31 of this word
+        const uint32_t i0 = inv[wq], i1 = inv[wq + 1], l0 = low[wq], l1 = low[wq + 1];
+        const uint32_t c0 = codes[2 * wq], c1 = codes[2 * wq + 1], c2 = codes[2 * wq + 2];
+        const uint32_t inr = topbits(p1 - base) & ~topbits(p0 - base);      // positions of the word inside [p0, p1)
+        const uint32_t e0 = i0 | (mask_host ? l0 : 0u), e1 = i1 | (mask_host ? l1 : 0u);
+        const uint64_t V = ~((uint64_t(e0) << 32) | e1);                    // countable bases; position base+j at bit 63-j
+        uint64_t F = V;                                                     // ... that start a run of kmax of them
+        for (int s = 1; s < kmax; ++s) F &= V << s;
+        const uint32_t fullm = uint32_t(F >> 32) & inr;
+        const uint64_t lo64 = (uint64_t(c0) << 32) | c1, hi64 = (uint64_t(c1) << 32) | c2;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (fullm & (0x80000000u >> j)) {
+                const uint32_t c16 = uint32_t((j < 16 ? lo64 : hi64) >> (48 - 2 * (j & 15))) & 0xFFFFu;
+                const uint32_t code = c16 >> shK;
+                if ((code & halfbit) == (half ? halfbit : 0u)) atomicAdd(&hist[code & (nbins - 1)], 1u);
+            }
         }
         if (half == 0) {
-            const uint32_t pad8 = inv8 & low8;
-            const uint32_t real = ((pad8 >> 7) & 1u) ^ 1u;
-            tot += real;
-            nn += real & (((inv8 | low8) >> 7) & 1u);            // not an uppercase A/T/G/C (countN, L106-118)
-            kpos += ((pad8 >> (8 - kmax)) == 0u) ? 1u : 0u;       // a K-mer can start here (L329)
+            // the few countable positions whose run is shorter than kmax: straight to the global tables
+            uint32_t shortm = uint32_t(V >> 32) & ~uint32_t(F >> 32) & inr;
+            while (shortm) {
+                const int j = __clz(int(shortm));
+                shortm &= ~(0x80000000u >> j);
+                const int run = __clzll((long long)(~(V << j)));            // < kmax here
+                if (run >= kmin) {
+                    const uint32_t c16 = uint32_t((j < 16 ? lo64 : hi64) >> (48 - 2 * (j & 15))) & 0xFFFFu;
+                    atomicAdd(&raw[table_offset(kmin, run) + (c16 >> (16 - 2 * run))], 1ull);
+                }
+            }
+            const uint64_t NP = ~((uint64_t(i0 & l0) << 32) | (i1 & l1));   // not a PAD
+            uint64_t G = NP;                                                // a K-mer can start here (L329): no PAD in reach
+            for (int s = 1; s < kmax; ++s) G &= NP << s;
+            const uint32_t real = uint32_t(NP >> 32) & inr;
+            tot += __popc(real);
+            nn += __popc(real & (i0 | l0));                                 // not an uppercase A/T/G/C (countN, L106-118)
+            kpos += __popc(uint32_t(G >> 32) & inr);
         }
     }
     if (half == 0) {                     // wave-level reduction of the three scalars, one atomic per wave
