@@ -577,7 +577,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
             };
             {
                 int x = ks - 1;
-                for (; x >= kmin && x > 3; --x) {               // wide levels: all waves, one barrier each
+#ifndef FRISK_MARG_WIDE
+#define FRISK_MARG_WIDE 3
+#endif
+                for (; x >= kmin && x > FRISK_MARG_WIDE; --x) { // wide levels: all waves, one barrier each
                     marg_level(x, tid, NT);
                     __syncthreads();
                 }
