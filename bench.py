@@ -30,6 +30,24 @@ KMIN, KMAX, W, INC = 1, 8, 5000, 1000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def host_cpu():
+    """(model name, logical CPUs of the box, CPUs this process may run on)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return model, os.cpu_count(), usable
+
+
 def cpu_baseline(engine, names_seq0_len, n_windows):
     """Time oracle/frisk_oracle.py (the reference-shaped Python restatement, 1 core) on the first
     `n_windows` candidate windows of scaffold 0, against the profile the GPU just built.
@@ -204,6 +222,8 @@ def main():
         }
         if opts.cpu_windows > 0:
             cb, worst, np_line, c_line = cpu_baseline(eng, lens[0], opts.cpu_windows)
+            model, logical, usable = host_cpu()
+            cb["host_cpu"] = "%s, %d logical CPUs (%d usable by this process)" % (model, logical, usable)
             out["cpu_baseline"] = cb
             out["cpu_baseline_numpy"] = np_line
             out["cpu_baseline_c"] = c_line
