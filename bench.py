@@ -195,12 +195,15 @@ def main():
         # algorithmic bytes of one scan launch: 2-bit bases once, 40 B per emitted row, genome table once
         b_alg = 0.25 * total_bases + 40.0 * rows + 8.0 * sum(4 ** x for x in range(KMIN, KMAX + 1))
         achieved = b_alg / (scan_avg * 1e-3) / 1e9
+        issue = {}
         traffic = None      # HBM bytes per scan launch from PMC counters (collected offline with rocprofv3, same workload)
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("workload_bases_per_gpu") == total_bases and tj.get("candidate_windows_per_gpu") == n_cand:
                 traffic = tj["hbm_bytes_per_launch"]
+                issue = {k: tj[k] for k in ("SQ_INSTS_VALU_per_launch", "SQ_ACTIVE_INST_ANY_over_SQ_WAVE_CYCLES",
+                                            "waves_per_simd") if k in tj}
         out = {
             "metric": "windows/sec (k=1..8, w=5kb, s=1kb)", "value": rows_all / (elapsed / opts.steps),
             "unit": "windows/s", "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
@@ -212,11 +215,12 @@ def main():
                        "bases_per_gpu": total_bases, "candidate_windows_per_gpu": n_cand, "rows_per_gpu_rank0": rows,
                        "shard_scale": opts.shard_scale},
             "gbases_per_s": bases_all / (elapsed / opts.steps) / 1e9,
+            "windowed_gbases_per_s": rows_all * W / (elapsed / opts.steps) / 1e9,      # rows x w: bases looked at, overlap counted
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
             "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_kernel", "algorithmic_bytes_per_launch": b_alg,
+                         "kernel": "scan_kernel", "algorithmic_bytes_per_launch": b_alg, "issue_counters": issue,
                          "note": "the path is not HBM-limited at any plausible rate (290 B/window); the binding "
                                  "limits are LDS atomics and FP64 divide/log issue - see DESIGN.md"},
         }
