@@ -16,6 +16,7 @@
 #include "frisk_device.h"
 #include "profile_kernels.h"
 #include "scan_kernel.h"
+#include "scan_big_kernel.h"
 #include "synth_kernel.h"
 
 namespace {
@@ -60,6 +61,7 @@ struct frisk_ctx {
     // profile
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
     DevBuf<double> d_ig, d_logtab;
+    DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
     int64_t total_len = 0, ex_max = 0, nn_total = 0;
     bool profile_final = false;
 
@@ -187,7 +189,7 @@ extern "C" {
 const char* frisk_version(void) { return "frisk_hip 0.1 (gfx950)"; }
 
 int frisk_supported(int kmin, int kmax, int64_t max_window) {
-    return (kmin >= 1 && kmin <= kmax && kmax <= FRISK_MAX_K && max_window >= 1 && max_window <= 65535) ? 1 : 0;
+    return (kmin >= 1 && kmin <= kmax && kmax <= FRISK_MAX_K && max_window >= 1 && max_window <= 0x7FFFFFFF) ? 1 : 0;
 }
 
 int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
@@ -240,7 +242,7 @@ void frisk_destroy(frisk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_ascii.release(); c->d_codes.release(); c->d_inv.release(); c->d_low.release();
-    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_desc.release();
+    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
     c->o_kld.release(); c->o_gc.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
@@ -555,7 +557,6 @@ int frisk_scan_plan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_
     if (!c) return FRISK_E_ARG;
     if (!c->have_seq) return fail(c, FRISK_E_STATE, "frisk_scan_plan: no resident sequence batch");
     if (w < 1 || inc < 1) return fail(c, FRISK_E_ARG, "window length and increment must be >= 1");
-    if (w > 65535) return fail(c, FRISK_E_ARG, "window length > 65535 is not supported by the LDS kernel");
     const bool all = (flags & FRISK_SCAN_SCAFFOLDS_ALL) != 0;
     if (c->plan_w == w && c->plan_inc == inc && ((c->plan_flags ^ flags) & FRISK_SCAN_SCAFFOLDS_ALL) == 0) {
         if (n_candidates) *n_candidates = c->plan_ncand;
@@ -577,7 +578,7 @@ int frisk_scan_plan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_
     ScafDesc& sentinel = c->h_desc[size_t(c->n_seq)];       // keeps the binary search in range
     sentinel.off = c->padded_len; sentinel.size = 0; sentinel.cand0 = cand; sentinel.ncand = 0; sentinel.kind = 0;
     sentinel.pad_ = 0;
-    if (maxwin > 65535) return fail(c, FRISK_E_ARG, "a rescued scaffold is longer than 65535 bases");
+    if (maxwin > 0x7FFFFFFF) return fail(c, FRISK_E_ARG, "a window longer than 2^31-1 bases");
     HIPC(c, c->d_desc.reserve(c->h_desc.size()));
     HIPC(c, hipMemcpyAsync(c->d_desc.p, c->h_desc.data(), c->h_desc.size() * sizeof(ScafDesc), hipMemcpyHostToDevice,
                            c->stream));
@@ -640,7 +641,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.lv = shared_level(c->kmin, c->kmax);
     LdsLayout L = make_layout(c->kmin, c->kmax, P.orphan_cap, P.lv);
     if (L.total > 160 * 1024 && P.lv) { P.lv = 0; L = make_layout(c->kmin, c->kmax, P.orphan_cap, 0); }
-    if (L.total > 160 * 1024) return fail(c, FRISK_E_ARG, "window too long for the 160 KB LDS of one workgroup");
+    if (c->plan_maxwin <= 65535 && L.total > 160 * 1024)
+        return fail(c, FRISK_E_ARG, "window too long for the 160 KB LDS of one workgroup");
     const int wg_per_cu = std::max(1, std::min(2, int(160 * 1024 / L.total)));
     int grid = int(std::min<int64_t>(n, int64_t(c->num_cu) * wg_per_cu));
     if (grid >= 8) grid &= ~7;
@@ -655,6 +657,16 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
 
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
+    if (c->plan_maxwin > 65535) {
+        // windows beyond the 16-bit LDS counters: 32-bit tables of all orders in a global scratch slice per workgroup
+        const int big_grid = int(std::min<int64_t>(n, c->num_cu));
+        const int64_t stride = (c->nprof + 3) / 4 * 4;
+        HIPC(c, c->d_big.reserve(size_t(big_grid) * size_t(stride)));
+        HIPC(c, hipMemsetAsync(c->d_big.p, 0, size_t(big_grid) * size_t(stride) * 4, c->stream));
+        if (debug) scan_big_kernel<true><<<big_grid, FRISK_BIG_NT, 0, c->stream>>>(P, c->d_big.p, stride);
+        else scan_big_kernel<false><<<big_grid, FRISK_BIG_NT, 0, c->stream>>>(P, c->d_big.p, stride);
+        e = hipGetLastError();
+    } else
 #define FRISK_LAUNCH(NT_, K8_, ITS_, DBG_) e = launch_scan<NT_, K8_, ITS_, DBG_>(P, grid, L.total, c->stream)
     if (k8) {
         if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }

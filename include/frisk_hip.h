@@ -50,7 +50,8 @@ enum {
 
 const char* frisk_version(void);
 
-/* Library limits for (kmin,kmax,window length); 0 = unsupported.  kmax <= 8, window <= 65535. */
+/* Library limits for (kmin,kmax,window length); 0 = unsupported.  kmax <= 8; windows up to 65535 bases run in LDS,
+ * longer ones (up to 2^31-1) on a slower path with 32-bit tables in global memory. */
 int frisk_supported(int kmin, int kmax, int64_t max_window);
 
 /* Context: device ordinal, word sizes -m/-k (L1197-1206). */

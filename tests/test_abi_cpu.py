@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.frisk_version()
     assert lib.frisk_supported(1, 8, 5000) == 1
     assert lib.frisk_supported(1, 9, 5000) == 0 and lib.frisk_supported(3, 2, 5000) == 0
-    assert lib.frisk_supported(1, 8, 70000) == 0
+    assert lib.frisk_supported(1, 8, 70000) == 1 and lib.frisk_supported(1, 8, 2 ** 31) == 0 and lib.frisk_supported(1, 8, 0) == 0
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):

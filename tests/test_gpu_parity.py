@@ -204,8 +204,9 @@ def test_error_paths_and_edge_batches():
         with pytest.raises(_ffi.FriskHipError) as ei:
             e.scan(100, 10, rip=True)                        # kmin > 2: no dinucleotide table (reference L478)
         assert ei.value.code == _ffi.E_ARG
+        assert len(e.scan(70000, 10)) == 0                   # long windows are supported (global-memory path): no candidates here
         with pytest.raises(_ffi.FriskHipError) as ei:
-            e.scan(70000, 10)
+            e.scan(0, 10)
         assert ei.value.code == _ffi.E_ARG
         with pytest.raises(_ffi.FriskHipError):
             e.profile_add(pos_begin=5, pos_end=10 ** 9)
@@ -402,8 +403,8 @@ def test_full_size_rows_against_c_oracle(shape):
                                              (2, 7, 65535, 20000), (1, 4, 60000, 7000), (2, 8, 9000, 4000),
                                              (4, 8, 20000, 9000), (1, 6, 12000, 5000), (5, 5, 10000, 3000)])
 def test_long_windows_against_c_oracle(kmin, kmax, w, inc, want_rip):
-    """Windows beyond the unrolled fast paths (generic kernel), up to the 65 535-base limit, with many invalid runs
-    (hence a long orphan list at K = 8, which displaces the shared prefix tables in LDS)."""
+    """Windows beyond the unrolled fast paths (generic kernel), up to the 65 535 bases that 16-bit LDS counters hold, with
+    many invalid runs (hence a long orphan list at K = 8, which displaces the shared prefix tables in LDS)."""
     from oracle import frisk_oracle_c as OC
     rng = np.random.default_rng(w + kmax)
     seqs = []
@@ -433,5 +434,44 @@ def test_long_windows_against_c_oracle(kmin, kmax, w, inc, want_rip):
             for col in ("pi", "si", "cri"):
                 assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
         assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
-        with pytest.raises(Exception):
-            e.scan(65536, inc)
+
+
+@pytest.mark.parametrize("kmin,kmax,w,inc,scaffolds_all,rip", [
+    (1, 8, 65536, 30000, False, True), (1, 8, 100000, 60000, True, False), (2, 6, 250000, 100000, False, True),
+    (3, 8, 70000, 69000, True, False), (1, 3, 131072, 131072, False, True), (8, 8, 90000, 45000, False, False)])
+def test_windows_beyond_lds_counters_against_c_oracle(kmin, kmax, w, inc, scaffolds_all, rip):
+    """Windows longer than 65 535 bases take the global-memory path (scan_big_kernel.h: 32-bit tables of all orders, the
+    order-K table walked instead of the positions); same comparisons as everywhere, plus the count tables themselves."""
+    from oracle import frisk_oracle_c as OC
+    rng = np.random.default_rng(w + 7 * kmax + kmin)
+    seqs = []
+    for n in (700000, 2 * w + 12345, w + w // 3, 4000):
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n, p=[0.3, 0.2, 0.15, 0.35])
+        for a in rng.integers(0, max(1, n - 3000), size=12):
+            s[a:a + int(rng.integers(1, 2500))] = ord("N")
+        s[500:1500] |= 0x20
+        s[2000:2600] = ord("A")                                    # big counts
+        seqs.append(s.tobytes())
+    with make_engine(kmin, kmax) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        res = e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all, debug=True)
+        res2 = e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
+        osym, ometa = OC.genome_profile(seqs, kmin, kmax)
+        assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+        exp = OC.scan(seqs, OC.genome_ivom(osym, ometa, kmin, kmax), kmin, kmax, w, inc, scaffolds_all=scaffolds_all,
+                      rip=rip, debug=True)
+    k = np.nonzero(res.kept)[0]
+    assert len(k) == len(exp["kld"]) and len(k) >= 3
+    assert np.array_equal(res.seq_index[k], exp["seq"])
+    assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"])
+    assert np.array_equal(res.counts[k].astype(np.int64), exp["counts"].astype(np.int64))
+    assert np.array_equal(res.meta[k], exp["meta"])
+    assert np.array_equal(res.gc[k], exp["gc"])
+    assert np.array_equal(res.status[k] & 0xB, (exp["status"] & 0xA) | 1)
+    if rip:
+        for col in ("pi", "si", "cri"):
+            assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
+    assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
+    assert np.array_equal(res.kld, res2.kld, equal_nan=True) and np.array_equal(res.status, res2.status)
