@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _random_case(rng):
     kmax = int(rng.integers(1, 9))
     kmin = int(rng.integers(1, kmax + 1))
-    w = int(rng.choice([37, 64, 100, 333, 512, 1000, 2048, 2049, 5000, 5121, 8192, 8193, 12000]))
+    w = int(rng.choice([37, 64, 100, 333, 512, 1000, 2048, 2049, 5000, 5121, 8192, 8193, 12000, 66000]))
     inc = max(1, int(w * rng.choice([0.05, 0.2, 0.5, 0.9, 1.0, 1.6])))
     seqs = []
     for _ in range(int(rng.integers(1, 6))):
