@@ -310,7 +310,7 @@ __device__ inline void block_sum3(ExactSum& a, ExactSum& b, ExactSum& c, double*
 //          codes and IVOM values stay in registers between the passes.
 // ITS == 0: any length up to 65535; runtime loops, values recomputed in the last pass.
 template <int NT, bool K8, int ITS, bool DEBUG>
-__global__ __launch_bounds__(NT) void scan_kernel(const ScanParams P) {
+__global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const ScanParams P) {
     constexpr int NW = NT / 64;
     constexpr int NREG = ITS > 0 ? ITS : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];

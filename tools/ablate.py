@@ -10,12 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "frisk_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out", "ablate")
 
+CHILD_K = int(os.environ.get("ABLATE_K", "8"))
 CHILD = r'''
 import sys, json
 sys.path.insert(0, %r)
 from frisk_amd import Engine, synth
 lens = [int(x*%f) for x in synth.c5_shard_lens(8, 0)]
-e = Engine(1, 8)
+e = Engine(1, %d)
 e.synth(lens, seed=0xC5, island_frac=0.02, n_frac=0.07)
 e.profile_reset(); e.profile_add(); e.profile_finalize()
 ts = []
@@ -36,7 +37,7 @@ def main():
                         "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", lib,
                         os.path.join(CSRC, "frisk_abi.hip"), "-lz"] + defs, check=True)
         env = dict(os.environ, FRISK_HIP_LIB=lib)
-        out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, scale)], env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, scale, CHILD_K)], env=env, capture_output=True, text=True)
         print(spec, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:], flush=True)
         for line in out.stderr.splitlines():
             if line.startswith("[stamps]"):
