@@ -161,9 +161,9 @@ void plan_scaffold(int64_t size, int32_t w, int32_t inc, bool all, int64_t& ncan
     }
 }
 
-template <int NT, bool K8, int ITS, bool DEBUG>
+template <int NT, bool K8, int ITS, bool DEBUG, bool QUART = false>
 hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st) {
-    auto kern = scan_kernel<NT, K8, ITS, DEBUG>;
+    auto kern = scan_kernel<NT, K8, ITS, DEBUG, QUART>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(lds));
     if (e != hipSuccess) return e;
@@ -655,6 +655,10 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     const int64_t need = (c->plan_maxwin + 511) / 512;
     const int its = need <= 4 ? 4 : need <= 10 ? 10 : need <= 16 ? 16 : 0;
 
+    // quarter-table form of the K = 8 fast paths (two workgroups per CU) - FRISK_K8_ONE_WG=1 keeps the one-workgroup form
+    P.list_cap = int32_t((c->plan_maxwin + 7) / 8 * 8);
+    const LdsLayout Lq = make_layout(c->kmin, c->kmax, P.orphan_cap, P.lv, true, P.list_cap);
+    const bool quart = k8 && c->plan_maxwin <= 5120 && Lq.total <= 80 * 1024 && !std::getenv("FRISK_K8_ONE_WG");
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
     if (c->plan_maxwin > 65535) {
@@ -668,7 +672,15 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         e = hipGetLastError();
     } else
 #define FRISK_LAUNCH(NT_, K8_, ITS_, DBG_) e = launch_scan<NT_, K8_, ITS_, DBG_>(P, grid, L.total, c->stream)
-    if (k8) {
+    if (k8 && !debug && quart) {
+        // K = 8 with TWO independent 256-thread workgroups per CU: the order-8 table serves one leading base at a time
+        // (32 KiB), the window's max-mers are bucketed by leading base and handled in four passes (scan_kernel.h, QUART)
+        grid = int(std::min<int64_t>(n, int64_t(c->num_cu) * 2));
+        if (grid >= 8) grid &= ~7;
+        P.chunk = int32_t(std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(grid) * 8), 8)));
+        if (c->plan_maxwin <= 2048) e = launch_scan<256, true, 8, false, true>(P, grid, Lq.total, c->stream);
+        else e = launch_scan<256, true, 20, false, true>(P, grid, Lq.total, c->stream);
+    } else if (k8) {
         if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
         else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
         else if (its == 10) FRISK_LAUNCH(512, true, 10, false);

@@ -56,6 +56,7 @@ struct ScanParams {
     int32_t chunk;            // consecutive candidates handed to a workgroup at a time
     int32_t orphan_cap;       // capacity of the orphan list (entries)
     int32_t lv;               // shared_level(), or 0 when the prefix tables do not fit beside a long window's orphan list
+    int32_t list_cap;         // entries of the bucketed max-mer list (quarter-table kernels; >= longest window)
     int32_t nprof;            // profile length (debug dump stride)
     // outputs, indexed by (candidate - c0)
     int32_t* seq_index;
@@ -105,6 +106,8 @@ struct LdsLayout {
     uint32_t rtab;      // f64[16]: 4^x / ((S-(x-1))*2) per order x (window constants)
     uint32_t logtab;    // f64[2*FRISK_LOGTAB_N]: {1/c_i, ln c_i}, written once per workgroup
     uint32_t misc;      // 2 x 16 u32 counters (double-buffered by window parity) + reduction scratch
+    uint32_t list;      // u16[list_cap]: the window's max-mer codes bucketed by leading base (quarter-table kernels only)
+    uint32_t t8_bytes;  // 128 KiB, or 32 KiB when the order-8 table holds ONE leading base at a time
     uint32_t total;
 };
 
@@ -115,13 +118,15 @@ __host__ __device__ inline int shared_level(int kmin, int kmax) { return (kmin <
 #define FRISK_LOGTAB_N 128
 #define FRISK_MISC_BYTES (2 * FRISK_MISC_SLOTS * 4 + 16 * 6 * 8)       // counters x2, scratch (16 waves x 3 x 128 bit)
 
-__host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap, int lv) {
+__host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap, int lv, bool quart = false,
+                                                 int list_cap = 0) {
     LdsLayout L;
     const bool k8 = (kmax == 8);
     const int ks = k8 ? 6 : kmax;
     uint32_t o = 0;
     L.t8 = o;
-    if (k8) o += FRISK_T8_BYTES;
+    L.t8_bytes = k8 ? (quart ? FRISK_T8_BYTES / 4 : FRISK_T8_BYTES) : 0;
+    o += L.t8_bytes;
     L.small = o;
     int64_t bins = (ks >= kmin) ? table_offset(kmin, ks + 1) : 0;
     L.small_bytes = uint32_t((bins * 2 + 15) / 16 * 16);
@@ -138,15 +143,19 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
     o += FRISK_LOGTAB_N * 16;
     L.misc = o;
     o += FRISK_MISC_BYTES;
+    L.list = o;
+    if (quart) o += uint32_t(list_cap * 2 + 15) / 16 * 16;
     L.total = (o + 15) / 16 * 16;
     return L;
 }
 
 // misc counter slots
-enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS };
+enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS, M_CLS = 8 /* ..11: max-mers per leading base */ };
 
-template <bool K8>
+// QUART: the order-8 table holds the max-mers of ONE leading base at a time (index = the low 14 bits of the code)
+template <bool K8, bool QUART = false>
 struct WinTables {
+    static constexpr uint32_t M8 = QUART ? 0x3FFFu : 0xFFFFu, M7 = QUART ? 0xFFFu : 0x3FFFu;
     const uint16_t* t8_16;
     const uint16_t* small16;
     const uint16_t* orph;
@@ -169,9 +178,9 @@ struct WinTables {
     template <int ORPH = 0>
     __device__ inline uint32_t count(int x, uint32_t c) const {
         if (K8) {
-            if (x == 8) return t8_16[c];
+            if (x == 8) return t8_16[QUART ? (c & M8) : c];
             if (x == 7) {
-                const uint2 q = *reinterpret_cast<const uint2*>(t8_16 + 4 * c);   // 4 children, 8-byte aligned
+                const uint2 q = *reinterpret_cast<const uint2*>(t8_16 + 4 * (QUART ? (c & M7) : c));   // 4 children, 8-byte aligned
                 uint32_t s = (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16);
                 return s + orphans<ORPH>(c);
             }
@@ -309,8 +318,12 @@ __device__ inline void block_sum3(ExactSum& a, ExactSum& b, ExactSum& c, double*
 // ITS > 0: the window has at most ITS*NT positions; per-position loops are fully unrolled and the per-position
 //          codes and IVOM values stay in registers between the passes.
 // ITS == 0: any length up to 65535; runtime loops, values recomputed in the last pass.
-template <int NT, bool K8, int ITS, bool DEBUG>
+// QUART (K = 8, two 256-thread workgroups per CU): the order-8 table is 32 KiB and serves one leading base at a time;
+//          the window's max-mer codes are bucketed by leading base into an LDS list and counted / scored / re-zeroed in
+//          four passes with full lanes.
+template <int NT, bool K8, int ITS, bool DEBUG, bool QUART = false>
 __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const ScanParams P) {
+    static_assert(!QUART || (K8 && ITS > 0 && !DEBUG), "the quarter-table form exists for the K = 8 fast paths only");
     constexpr int NW = NT / 64;
     constexpr int NREG = ITS > 0 ? ITS : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -318,7 +331,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     const int lane = tid & 63;
     const int kmin = P.kmin;
     const int kmax = K8 ? 8 : P.kmax;                   // compile-time at K = 8: the order loops unroll
-    const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap, P.lv);
+    const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap, P.lv, QUART, P.list_cap);
+    uint16_t* qlist = reinterpret_cast<uint16_t*>(lds + L.list);
     uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L.t8);
     uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
     uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L.small);
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     const int kshift = 16 - 2 * kmax;
 
     // one-time clear of the histograms and counters
-    if (K8) for (int i = tid; i < FRISK_T8_BYTES / 16; i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
+    if (K8) for (int i = tid; i < int(L.t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 2 * FRISK_MISC_SLOTS) misc_base[tid] = 0;
     if (tid < FRISK_LOGTAB_N) logtab[tid] = reinterpret_cast<const double2*>(P.log_tab)[tid];
@@ -403,6 +417,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             // (done before the N filter is known: 93 % of windows pass it, the others are cleaned up after stage 2)
             unsigned long long repmask = 0;
             uint32_t c16v[NREG];
+            unsigned long long q_off = 0;       // QUART: four 16-bit fields - where this lane's next max-mer of each leading base goes
+            uint32_t q_fullm = 0;               // QUART: the lane's positions that start a max-mer
             const bool tally_by_ballot = (kmin != 1);
             {
                 uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
@@ -490,8 +506,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                                     const uint32_t b = off_full + (c16 >> 4);
                                     atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
                                 }
-                                const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
-                                if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                                if constexpr (!QUART) {
+                                    const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
+                                    if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
+                                }
                             } else {
                                 const uint32_t b = off_full + (c16 >> sh_full);
                                 const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
@@ -506,6 +524,31 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     const uint32_t ntop = __popc(fullm);
 #pragma unroll
                     for (int b = 0; (1 << b) <= ITS; ++b) nvalid += uint32_t(__popcll(__ballot((ntop >> b) & 1u))) << b;
+                    if constexpr (QUART) {
+                        // bucket bookkeeping: the lane's max-mers per leading base (four 16-bit fields), an inclusive scan over
+                        // the wave, ONE atomic per wave and leading base for the wave's share of the window's totals
+                        unsigned long long cnt4 = 0;
+#pragma unroll
+                        for (int it = 0; it < ITS; ++it)
+                            if (fullm & (0x80000000u >> it)) cnt4 += 1ull << (16 * (c16v[it] >> 14));
+                        unsigned long long inc4 = cnt4;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const unsigned long long up = __shfl_up(inc4, o);
+                            if (lane >= o) inc4 += up;
+                        }
+                        const unsigned long long wave4 = __shfl(inc4, 63);
+                        unsigned long long base4 = 0;
+                        if (lane == 0) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const uint32_t t = uint32_t(wave4 >> (16 * b)) & 0xFFFFu;
+                                if (t) base4 |= (unsigned long long)(atomicAdd(&misc[M_CLS + b], t)) << (16 * b);
+                            }
+                        }
+                        q_off = __shfl(base4, 0) + inc4 - cnt4;
+                        q_fullm = fullm;
+                    }
                     if (tally_by_ballot) {          // kmin > 1: no order-1 table to read the composition from
                         const uint32_t upm = actm & vld & ~alow;
 #pragma unroll
@@ -548,12 +591,33 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             }
             __syncthreads();
             if (tid < FRISK_MISC_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
+            uint32_t q_tot[4] = {0, 0, 0, 0}, q_start[4] = {0, 0, 0, 0};   // QUART: the four buckets of the list
+            if constexpr (QUART) {
+                uint32_t run = 0;
+                unsigned long long start4 = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    q_tot[b] = __builtin_amdgcn_readfirstlane(misc[M_CLS + b]);
+                    q_start[b] = run;
+                    start4 |= (unsigned long long)run << (16 * b);
+                    run += q_tot[b];
+                }
+                unsigned long long off4 = q_off + start4;
+#pragma unroll
+                for (int it = 0; it < ITS; ++it) {
+                    if (q_fullm & (0x80000000u >> it)) {
+                        const uint32_t cls = c16v[it] >> 14;
+                        qlist[uint32_t(off4 >> (16 * cls)) & 0xFFFFu] = uint16_t(c16v[it]);
+                        off4 += 1ull << (16 * cls);
+                    }
+                }
+            }
             auto code16_at = [&](int it) -> uint32_t {
                 if (ITS > 0) return c16v[it];
                 return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT);
             };
             auto zero_own_bins = [&]() {        // representatives zero their max-mer bin (K8; the small tables are
-                if (K8) {                       // cleared wholesale)
+                if (K8 && !QUART) {             // cleared wholesale; the quarter-table passes re-zero as they go)
 #pragma unroll
                     for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it)
                         if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code16_at(it)] = 0;
@@ -629,7 +693,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
 
             STOP_AFTER(2, small16[tid & 3] + nvalid_top)
 
-            WinTables<K8> T;
+            WinTables<K8, QUART> T;
             T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
             T.small16 = small16;
             T.orph = orph; T.n_orph = n_orph;
@@ -741,7 +805,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                         // children summed for its 7-mer prefix
                         const uint32_t c6 = T.template count<PLAIN>(6, code >> 4);
                         const uint32_t q7 = code >> 2;
-                        const uint2 ch = *reinterpret_cast<const uint2*>(T.t8_16 + 4 * q7);
+                        const uint2 ch = *reinterpret_cast<const uint2*>(T.t8_16 + 4 * (QUART ? (q7 & 0xFFFu) : q7));
                         const uint64_t both = (uint64_t(ch.y) << 32) | ch.x;
                         const uint32_t c8 = uint32_t(both >> ((code & 3u) * 16)) & 0xFFFFu;
                         uint32_t c7 = (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
@@ -778,35 +842,80 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             auto only_rep = [](bool rep, double x) -> double {
                 return __hiloint2double(rep ? __double2hiint(x) : 0, __double2loint(x));
             };
-            auto stage4 = [&](auto plain_c, auto lv_c) __attribute__((always_inline)) {
-#pragma unroll
-                for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
-                    // (iterations past the window are not skipped: their lanes are clamped and masked, and a
-                    //  branch here would split the unrolled body into blocks the scheduler cannot interleave)
-                    const bool rep = (repmask >> it) & 1ull;
-                    if (ITS == 0 && !rep) continue;
-                    const uint32_t code = code16_at(it) >> kshift;
-                    const double Ig = P.ig[code];                           // unconditional gather (code < 4^K always)
-                    // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
-                    double A;
-                    const double Wd = window_ivom(code, plain_c, lv_c, A);
-                    const double ratio = div_exact(A, Wd * Ig);
-                    const double Iw = ratio * Ig;
-                    // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
+            // one max-mer: genome side gathered, window side from the tables, three exact additions
+            auto score_one = [&](uint32_t code, bool rep, auto plain_c, auto lv_c) __attribute__((always_inline)) {
+                const double Ig = P.ig[code];                               // unconditional gather (code < 4^K always)
+                // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
+                double A;
+                const double Wd = window_ivom(code, plain_c, lv_c, A);
+                const double ratio = div_exact(A, Wd * Ig);
+                const double Iw = ratio * Ig;
+                // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
 #ifdef FRISK_LOG_FDLIBM
-                    const double t = Iw * log_pos(ratio);
+                const double t = Iw * log_pos(ratio);
 #else
-                    const double t = Iw * log_tab_pos(ratio, logtab);
+                const double t = Iw * log_tab_pos(ratio, logtab);
 #endif
-                    exact_add(accw, only_rep(rep, Iw));
-                    exact_add(accg, only_rep(rep, Ig));
-                    exact_add(acct, only_rep(rep, t));
+                exact_add(accw, only_rep(rep, Iw));
+                exact_add(accg, only_rep(rep, Ig));
+                exact_add(acct, only_rep(rep, t));
+            };
+            auto stage4 = [&](auto plain_c, auto lv_c) __attribute__((always_inline)) {
+                if constexpr (QUART) {
+                    // four passes, one per leading base: count the bucket's max-mers into the quarter table (electing
+                    // representatives), score them, re-zero the bins.  Thread t takes entries t, t+NT, ... of the bucket in all
+                    // three loops, so its representative flags stay in a register.
+                    uint16_t* t8q = reinterpret_cast<uint16_t*>(t8);
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t nb = q_tot[b];
+                        const uint16_t* mine = qlist + q_start[b];
+                        uint32_t reps = 0;
+                        int k = 0;
+                        for (uint32_t e = tid; e < nb; e += NT, ++k) {
+                            const uint32_t idx = uint32_t(mine[e]) & 0x3FFFu;
+                            const uint32_t old = atomicAdd(&t8[idx >> 1], 1u << ((idx & 1u) * 16));
+                            if (((old >> ((idx & 1u) * 16)) & 0xFFFFu) == 0) reps |= 1u << k;
+                        }
+                        __syncthreads();
+                        // FRISK_Q_UNROLL entries per iteration so that their gather / division / log chains overlap (a short tail
+                        // scores its first entry again as a non-representative: that adds exactly nothing)
+#ifndef FRISK_Q_UNROLL
+#define FRISK_Q_UNROLL 1      // measured: 1 -> 4.67 ms, 2 -> 4.75, 3 -> 4.74, 5 -> 5.15 (quarter-scale shard): a masked tail entry costs full work
+#endif
+                        k = 0;
+                        for (uint32_t e = tid; e < nb; e += FRISK_Q_UNROLL * NT, k += FRISK_Q_UNROLL) {
+                            uint32_t codes[FRISK_Q_UNROLL];
+                            bool on[FRISK_Q_UNROLL];
+#pragma unroll
+                            for (int u = 0; u < FRISK_Q_UNROLL; ++u) {
+                                const bool have = e + u * NT < nb;
+                                codes[u] = mine[have ? e + u * NT : e];
+                                on[u] = have && ((reps >> (k + u)) & 1u);
+                            }
+#pragma unroll
+                            for (int u = 0; u < FRISK_Q_UNROLL; ++u) score_one(codes[u], on[u], plain_c, lv_c);
+                        }
+                        __syncthreads();
+                        k = 0;
+                        for (uint32_t e = tid; e < nb; e += NT, ++k)
+                            if ((reps >> k) & 1u) t8q[uint32_t(mine[e]) & 0x3FFFu] = 0;
+                        if (b < 3) __syncthreads();     // (after the last pass the block sum's barrier does it)
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
+                        // (iterations past the window are not skipped: their lanes are clamped and masked, and a
+                        //  branch here would split the unrolled body into blocks the scheduler cannot interleave)
+                        const bool rep = (repmask >> it) & 1ull;
+                        if (ITS == 0 && !rep) continue;
+                        score_one(code16_at(it) >> kshift, rep, plain_c, lv_c);
 #ifndef FRISK_S4_GROUP
 #define FRISK_S4_GROUP 2
 #endif
-                    // interleave at most FRISK_S4_GROUP positions: more overlap needs more live registers than the
-                    // 128 a 1024-thread workgroup leaves per lane, and the scheduler would spill
-                    if ((it % FRISK_S4_GROUP) == FRISK_S4_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+                        // interleave at most FRISK_S4_GROUP positions: more overlap needs more live registers than the
+                        // 128 a 1024-thread workgroup leaves per lane, and the scheduler would spill
+                        if ((it % FRISK_S4_GROUP) == FRISK_S4_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             };
             using orph1 = std::integral_constant<int, 1>;
