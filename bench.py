@@ -222,7 +222,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "scan_kernel", "algorithmic_bytes_per_launch": b_alg, "issue_counters": issue,
                          "note": "the path is not HBM-limited at any plausible rate (290 B/window); what binds is VALU issue "
-                                 "(FP64 scoring) + random LDS access and, at K = 8, the chip's power management - see DESIGN.md"},
+                                 "(FP64 scoring) + random LDS access + barrier waits - see DESIGN.md"},
         }
         if opts.cpu_windows > 0:
             cb, worst, np_line, c_line = cpu_baseline(eng, lens[0], opts.cpu_windows)
