@@ -150,18 +150,28 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
 }
 
 // misc counter slots
-enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS, M_CLS = 8 /* ..11: max-mers per leading base */ };
+enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS, M_CLS = 8 /* ..11: max-mers per leading base */, M_OVF = 12 };
 
-// QUART: the order-8 table holds the max-mers of ONE leading base at a time (index = the low 14 bits of the code)
-template <bool K8, bool QUART = false>
+// MODE = how the order-8 table is held (K = 8):
+//   0  all 4^8 bins, 16-bit (128 KiB)                                   - one workgroup per CU
+//   1  the bins of ONE leading base at a time, 16-bit (32 KiB, index = low 14 bits of the code)
+//   2  the bins of one leading BIT (two leading bases) at a time, 8-bit (32 KiB, index = low 15 bits) - valid while no
+//      max-mer occurs more than 255 times in the window; the kernel detects the overflow and redoes the pass in mode 1
+template <bool K8, int MODE = 0>
 struct WinTables {
-    static constexpr uint32_t M8 = QUART ? 0x3FFFu : 0xFFFFu, M7 = QUART ? 0xFFFu : 0x3FFFu;
+    static constexpr uint32_t M8 = MODE == 0 ? 0xFFFFu : (MODE == 1 ? 0x3FFFu : 0x7FFFu), M7 = M8 >> 2;
     const uint16_t* t8_16;
     const uint16_t* small16;
     const uint16_t* orph;
     int n_orph;
     uint32_t o0, o1, o2, o3;     // the first four orphan 7-mers (0xFFFFFFFF = none), wave-uniform
     int kmin;
+
+    template <int M2>
+    __device__ inline void same_window_as(const WinTables<K8, M2>& o) {
+        t8_16 = o.t8_16; small16 = o.small16; orph = o.orph; n_orph = o.n_orph;
+        o0 = o.o0; o1 = o.o1; o2 = o.o2; o3 = o.o3; kmin = o.kmin;
+    }
 
     // occurrences of the 7-mer `c` in the orphan list: a window has one orphan (its tail) plus one per invalid run -
     // almost always <= 4
@@ -173,17 +183,28 @@ struct WinTables {
         return s;
     }
 
+    // the max-mer's own count and the sum over the four children of its 7-mer prefix, from ONE aligned read
+    __device__ inline void top(uint32_t code, uint32_t& c8, uint32_t& children) const {
+        const uint32_t q7 = (code >> 2) & M7;
+        if (MODE == 2) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(t8_16) + 4 * q7);
+            c8 = (w >> ((code & 3u) * 8)) & 0xFFu;
+            children = __builtin_amdgcn_sad_u8(w, 0u, 0u);                   // sum of the four bytes
+        } else {
+            const uint2 ch = *reinterpret_cast<const uint2*>(t8_16 + 4 * q7);
+            const uint64_t both = (uint64_t(ch.y) << 32) | ch.x;
+            c8 = uint32_t(both >> ((code & 3u) * 16)) & 0xFFFFu;
+            children = (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
+        }
+    }
+
     // count of the x-mer `c` in the current window.  ORPH = what the caller knows about the window's orphan list:
     // 1: at most one entry (the usual case: the window's tail), 4: at most four, 0: anything
     template <int ORPH = 0>
     __device__ inline uint32_t count(int x, uint32_t c) const {
         if (K8) {
-            if (x == 8) return t8_16[QUART ? (c & M8) : c];
-            if (x == 7) {
-                const uint2 q = *reinterpret_cast<const uint2*>(t8_16 + 4 * (QUART ? (c & M7) : c));   // 4 children, 8-byte aligned
-                uint32_t s = (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16);
-                return s + orphans<ORPH>(c);
-            }
+            if (x == 8) { uint32_t c8, ch; top(c, c8, ch); return c8; }
+            if (x == 7) { uint32_t c8, ch; top(c << 2, c8, ch); return ch + orphans<ORPH>(c); }
         }
         return small16[table_offset(kmin, x) + c];
     }
@@ -693,7 +714,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
 
             STOP_AFTER(2, small16[tid & 3] + nvalid_top)
 
-            WinTables<K8, QUART> T;
+            WinTables<K8, (QUART ? 1 : 0)> T;
             T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
             T.small16 = small16;
             T.orph = orph; T.n_orph = n_orph;
@@ -791,7 +812,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             double r_hi[3];                                                 // r_6, r_7, r_8: the orders above the shared prefix
 #pragma unroll
             for (int x = 6; x <= 8; ++x) r_hi[x - 6] = r_of(x);
-            auto window_ivom = [&](uint32_t code, auto plain_c, auto lv_c, double& A_out) __attribute__((always_inline)) -> double {
+            auto window_ivom = [&](const auto& Tm, uint32_t code, auto plain_c, auto lv_c, double& A_out) __attribute__((always_inline)) -> double {
                 constexpr int PLAIN = decltype(plain_c)::value;
                 wsum_t W = 0;
                 double A = 0.0;
@@ -803,13 +824,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     if constexpr (K8) {
                         // orders 6, 7, 8 with ONE read of the max-mer table: the max-mer's own count is one of the four
                         // children summed for its 7-mer prefix
-                        const uint32_t c6 = T.template count<PLAIN>(6, code >> 4);
-                        const uint32_t q7 = code >> 2;
-                        const uint2 ch = *reinterpret_cast<const uint2*>(T.t8_16 + 4 * (QUART ? (q7 & 0xFFFu) : q7));
-                        const uint64_t both = (uint64_t(ch.y) << 32) | ch.x;
-                        const uint32_t c8 = uint32_t(both >> ((code & 3u) * 16)) & 0xFFFFu;
-                        uint32_t c7 = (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
-                        c7 += T.template orphans<PLAIN>(q7);
+                        const uint32_t c6 = Tm.template count<PLAIN>(6, code >> 4);
+                        uint32_t c8, c7;
+                        Tm.top(code, c8, c7);
+                        c7 += Tm.template orphans<PLAIN>(code >> 2);
                         const double d6 = double(c6), d7 = double(c7), d8 = double(c8);
                         W += (wsum_t(c6) << 12) + (wsum_t(c7) << 14) + (wsum_t(c8) << 16);
                         A = __builtin_fma(d6 * d6, r_hi[0], A);
@@ -818,14 +836,14 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     } else
 #pragma unroll
                     for (int x = LV + 1; x <= kmax; ++x) {
-                        const uint32_t cx = T.template count<PLAIN>(x, code >> (2 * (kmax - x)));
+                        const uint32_t cx = Tm.template count<PLAIN>(x, code >> (2 * (kmax - x)));
                         const double cd = double(cx);
                         W += wsum_t(cx) << (2 * x);
                         A = __builtin_fma(cd * cd, K8 ? r_hi[x - LV - 1] : rtab[x], A);    // K8: x is compile-time
                     }
                 } else {
                     for (int x = kmin; x <= kmax; ++x) {
-                        const uint32_t cx = T.template count<PLAIN>(x, code >> (2 * (kmax - x)));
+                        const uint32_t cx = Tm.template count<PLAIN>(x, code >> (2 * (kmax - x)));
                         const double cd = double(cx);
                         W += wsum_t(cx) << (2 * x);
                         A = __builtin_fma(cd * cd, rtab[x], A);
@@ -843,11 +861,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                 return __hiloint2double(rep ? __double2hiint(x) : 0, __double2loint(x));
             };
             // one max-mer: genome side gathered, window side from the tables, three exact additions
-            auto score_one = [&](uint32_t code, bool rep, auto plain_c, auto lv_c) __attribute__((always_inline)) {
+            auto score_one = [&](const auto& Tm, uint32_t code, bool rep, auto plain_c, auto lv_c) __attribute__((always_inline)) {
                 const double Ig = P.ig[code];                               // unconditional gather (code < 4^K always)
                 // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
                 double A;
-                const double Wd = window_ivom(code, plain_c, lv_c, A);
+                const double Wd = window_ivom(Tm, code, plain_c, lv_c, A);
                 const double ratio = div_exact(A, Wd * Ig);
                 const double Iw = ratio * Ig;
                 // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
@@ -862,11 +880,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             };
             auto stage4 = [&](auto plain_c, auto lv_c) __attribute__((always_inline)) {
                 if constexpr (QUART) {
-                    // four passes, one per leading base: count the bucket's max-mers into the quarter table (electing
-                    // representatives), score them, re-zero the bins.  Thread t takes entries t, t+NT, ... of the bucket in all
-                    // three loops, so its representative flags stay in a register.
-                    uint16_t* t8q = reinterpret_cast<uint16_t*>(t8);
-                    for (int b = 0; b < 4; ++b) {
+                    // Two passes, one per leading BIT, over 8-bit counters (32 KiB hold half of the k-mer space): count the
+                    // two buckets into the table (electing representatives), score them with full lanes, re-zero the bins.
+                    // Thread t takes entries t, t+NT, ... of the pass in all three loops, so its representative flags stay
+                    // in a register.  A max-mer that occurs more than 255 times overflows its byte: the count loop sees it
+                    // (old value 255), the pass is abandoned and redone bucket by bucket with 16-bit counters.
+                    uint16_t* t8h = reinterpret_cast<uint16_t*>(t8);
+                    uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
+                    WinTables<K8, 2> T8;
+                    T8.same_window_as(T);
+                    auto pass16 = [&](int b) {                                  // one leading base, 16-bit counters
                         const uint32_t nb = q_tot[b];
                         const uint16_t* mine = qlist + q_start[b];
                         uint32_t reps = 0;
@@ -877,29 +900,48 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                             if (((old >> ((idx & 1u) * 16)) & 0xFFFFu) == 0) reps |= 1u << k;
                         }
                         __syncthreads();
-                        // FRISK_Q_UNROLL entries per iteration so that their gather / division / log chains overlap (a short tail
-                        // scores its first entry again as a non-representative: that adds exactly nothing)
-#ifndef FRISK_Q_UNROLL
-#define FRISK_Q_UNROLL 1      // measured: 1 -> 4.67 ms, 2 -> 4.75, 3 -> 4.74, 5 -> 5.15 (quarter-scale shard): a masked tail entry costs full work
-#endif
                         k = 0;
-                        for (uint32_t e = tid; e < nb; e += FRISK_Q_UNROLL * NT, k += FRISK_Q_UNROLL) {
-                            uint32_t codes[FRISK_Q_UNROLL];
-                            bool on[FRISK_Q_UNROLL];
-#pragma unroll
-                            for (int u = 0; u < FRISK_Q_UNROLL; ++u) {
-                                const bool have = e + u * NT < nb;
-                                codes[u] = mine[have ? e + u * NT : e];
-                                on[u] = have && ((reps >> (k + u)) & 1u);
-                            }
-#pragma unroll
-                            for (int u = 0; u < FRISK_Q_UNROLL; ++u) score_one(codes[u], on[u], plain_c, lv_c);
-                        }
+                        for (uint32_t e = tid; e < nb; e += NT, ++k) score_one(T, uint32_t(mine[e]), (reps >> k) & 1u, plain_c, lv_c);
                         __syncthreads();
                         k = 0;
                         for (uint32_t e = tid; e < nb; e += NT, ++k)
-                            if ((reps >> k) & 1u) t8q[uint32_t(mine[e]) & 0x3FFFu] = 0;
-                        if (b < 3) __syncthreads();     // (after the last pass the block sum's barrier does it)
+                            if ((reps >> k) & 1u) t8h[uint32_t(mine[e]) & 0x3FFFu] = 0;
+                        __syncthreads();
+                    };
+                    for (int p = 0; p < 2; ++p) {
+                        const uint32_t nb = q_tot[2 * p] + q_tot[2 * p + 1];   // the two buckets are neighbours in the list
+                        const uint16_t* mine = qlist + q_start[2 * p];
+                        unsigned long long reps = 0;                            // <= 2 * ITS <= 40 entries per thread
+                        bool ovf = false;
+                        int k = 0;
+                        for (uint32_t e = tid; e < nb; e += NT, ++k) {
+                            const uint32_t idx = uint32_t(mine[e]) & 0x7FFFu;
+                            const uint32_t sh = (idx & 3u) * 8;
+                            const uint32_t old = (atomicAdd(&t8[idx >> 2], 1u << sh) >> sh) & 0xFFu;
+                            if (old == 0) reps |= 1ull << k;
+                            ovf |= (old == 255u);
+                        }
+#ifdef FRISK_Q_FORCE16      // experiment: always take the 16-bit four-pass route
+                        ovf = true;
+#endif
+                        if (ovf) misc[M_OVF] = 1u;
+                        __syncthreads();
+                        if (misc[M_OVF]) {                                      // (uniform) rare: low-complexity windows
+                            __syncthreads();                                    // everybody has seen the flag
+                            for (int i = tid; i < int(L.t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
+                            if (tid == 0) misc[M_OVF] = 0u;
+                            __syncthreads();
+                            pass16(2 * p);
+                            pass16(2 * p + 1);
+                        } else {
+                            k = 0;
+                            for (uint32_t e = tid; e < nb; e += NT, ++k) score_one(T8, uint32_t(mine[e]), (reps >> k) & 1ull, plain_c, lv_c);
+                            __syncthreads();
+                            k = 0;
+                            for (uint32_t e = tid; e < nb; e += NT, ++k)
+                                if ((reps >> k) & 1ull) t8b[uint32_t(mine[e]) & 0x7FFFu] = 0;
+                            if (p == 0) __syncthreads();    // (after the last pass the block sum's barrier does it)
+                        }
                     }
                 } else {
 #pragma unroll
@@ -908,7 +950,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                         //  branch here would split the unrolled body into blocks the scheduler cannot interleave)
                         const bool rep = (repmask >> it) & 1ull;
                         if (ITS == 0 && !rep) continue;
-                        score_one(code16_at(it) >> kshift, rep, plain_c, lv_c);
+                        score_one(T, code16_at(it) >> kshift, rep, plain_c, lv_c);
 #ifndef FRISK_S4_GROUP
 #define FRISK_S4_GROUP 2
 #endif
