@@ -862,88 +862,119 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             };
             // one max-mer: genome side gathered, window side from the tables, three exact additions
             auto score_one = [&](const auto& Tm, uint32_t code, bool rep, auto plain_c, auto lv_c) __attribute__((always_inline)) {
-                const double Ig = P.ig[code];                               // unconditional gather (code < 4^K always)
+#ifndef FRISK_ABL
+#define FRISK_ABL 0
+#endif
+                // (FRISK_ABL: diagnostic builds that drop one ingredient at a time - tools/ablate.py; results wrong by design)
+                const double Ig = (FRISK_ABL & 8) ? 1e-3 + 1e-9 * double(code) : P.ig[code];   // unconditional gather (code < 4^K always)
                 // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
                 double A;
-                const double Wd = window_ivom(Tm, code, plain_c, lv_c, A);
-                const double ratio = div_exact(A, Wd * Ig);
+                double Wd;
+                if (FRISK_ABL & 16) { A = 1e-4 * double(code & 1023u); Wd = double(code | 1u); }
+                else Wd = window_ivom(Tm, code, plain_c, lv_c, A);
+                const double ratio = (FRISK_ABL & 2) ? A * (Wd * Ig) : div_exact(A, Wd * Ig);
                 const double Iw = ratio * Ig;
                 // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
 #ifdef FRISK_LOG_FDLIBM
                 const double t = Iw * log_pos(ratio);
 #else
-                const double t = Iw * log_tab_pos(ratio, logtab);
+                const double t = (FRISK_ABL & 1) ? Iw * ratio : Iw * log_tab_pos(ratio, logtab);
 #endif
-                exact_add(accw, only_rep(rep, Iw));
-                exact_add(accg, only_rep(rep, Ig));
-                exact_add(acct, only_rep(rep, t));
+                if (FRISK_ABL & 4) {
+                    accw.hi += only_rep(rep, Iw); accg.hi += only_rep(rep, Ig); acct.hi += only_rep(rep, t);
+                } else {
+                    exact_add(accw, only_rep(rep, Iw));
+                    exact_add(accg, only_rep(rep, Ig));
+                    exact_add(acct, only_rep(rep, t));
+                }
             };
-            auto stage4 = [&](auto plain_c, auto lv_c) __attribute__((always_inline)) {
-                if constexpr (QUART) {
-                    // Two passes, one per leading BIT, over 8-bit counters (32 KiB hold half of the k-mer space): count the
-                    // two buckets into the table (electing representatives), score them with full lanes, re-zero the bins.
-                    // Thread t takes entries t, t+NT, ... of the pass in all three loops, so its representative flags stay
-                    // in a register.  A max-mer that occurs more than 255 times overflows its byte: the count loop sees it
-                    // (old value 255), the pass is abandoned and redone bucket by bucket with 16-bit counters.
-                    uint16_t* t8h = reinterpret_cast<uint16_t*>(t8);
-                    uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
-                    WinTables<K8, 2> T8;
-                    T8.same_window_as(T);
-                    auto pass16 = [&](int b) {                                  // one leading base, 16-bit counters
-                        const uint32_t nb = q_tot[b];
-                        const uint16_t* mine = qlist + q_start[b];
-                        uint32_t reps = 0;
-                        int k = 0;
-                        for (uint32_t e = tid; e < nb; e += NT, ++k) {
-                            const uint32_t idx = uint32_t(mine[e]) & 0x3FFFu;
-                            const uint32_t old = atomicAdd(&t8[idx >> 1], 1u << ((idx & 1u) * 16));
-                            if (((old >> ((idx & 1u) * 16)) & 0xFFFFu) == 0) reps |= 1u << k;
-                        }
+            // window-uniform decisions resolved OUTSIDE the scoring loops: bound on the orphan list, shared prefix in use
+            using orph1 = std::integral_constant<int, 1>;
+            using orph4 = std::integral_constant<int, 4>;
+            using orphN = std::integral_constant<int, 0>;
+            auto with_variant = [&](auto&& body) __attribute__((always_inline)) {
+                if (lv) {
+                    if (n_orph <= 1) body(orph1{}, std::true_type{});
+                    else if (n_orph <= 4) body(orph4{}, std::true_type{});
+                    else body(orphN{}, std::true_type{});
+                } else {
+                    if (n_orph <= 1) body(orph1{}, std::false_type{});
+                    else if (n_orph <= 4) body(orph4{}, std::false_type{});
+                    else body(orphN{}, std::false_type{});
+                }
+            };
+            if constexpr (QUART) {
+                // Two passes, one per leading BIT, over 8-bit counters (32 KiB hold half of the k-mer space): count the two
+                // buckets into the table (electing representatives), score them with full lanes, re-zero the bins.  Thread t
+                // takes entries t, t+NT, ... of the pass in all three loops, so its representative flags stay in a register.
+                // A max-mer that occurs more than 255 times overflows its byte: the count loop sees it (old value 255), the
+                // pass is abandoned and redone bucket by bucket with 16-bit counters.  (Counting and re-zeroing from the lanes'
+                // own registers instead of the list was measured: half-empty atomics, +9 %.)
+                uint16_t* t8h = reinterpret_cast<uint16_t*>(t8);
+                uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
+                WinTables<K8, 2> T8;
+                T8.same_window_as(T);
+                auto pass16 = [&](int b) {                                      // one leading base, 16-bit counters
+                    const uint32_t nb = q_tot[b];
+                    const uint16_t* lst = qlist + q_start[b];
+                    uint32_t reps = 0;
+                    int k = 0;
+                    for (uint32_t e = tid; e < nb; e += NT, ++k) {
+                        const uint32_t idx = uint32_t(lst[e]) & 0x3FFFu;
+                        const uint32_t old = atomicAdd(&t8[idx >> 1], 1u << ((idx & 1u) * 16));
+                        if (((old >> ((idx & 1u) * 16)) & 0xFFFFu) == 0) reps |= 1u << k;
+                    }
+                    __syncthreads();
+                    with_variant([&](auto plain_c, auto lv_c) {
+                        int kk = 0;
+                        for (uint32_t e = tid; e < nb; e += NT, ++kk) score_one(T, uint32_t(lst[e]), (reps >> kk) & 1u, plain_c, lv_c);
+                    });
+                    __syncthreads();
+                    k = 0;
+                    for (uint32_t e = tid; e < nb; e += NT, ++k)
+                        if ((reps >> k) & 1u) t8h[uint32_t(lst[e]) & 0x3FFFu] = 0;
+                    __syncthreads();
+                };
+#pragma nounroll
+                for (int p = 0; p < 2; ++p) {
+                    const uint32_t nb = q_tot[2 * p] + q_tot[2 * p + 1];       // the two buckets are neighbours in the list
+                    const uint16_t* mine = qlist + q_start[2 * p];
+                    unsigned long long reps = 0;                                // <= 2 * ITS <= 40 entries per thread
+                    bool ovf = false;
+                    int k = 0;
+                    for (uint32_t e = tid; e < nb; e += NT, ++k) {
+                        const uint32_t idx = uint32_t(mine[e]) & 0x7FFFu;
+                        const uint32_t sh = (idx & 3u) * 8;
+                        const uint32_t old = (atomicAdd(&t8[idx >> 2], 1u << sh) >> sh) & 0xFFu;
+                        if (old == 0) reps |= 1ull << k;
+                        ovf |= (old == 255u);
+                    }
+#ifdef FRISK_Q_FORCE16      // experiment: always take the 16-bit four-pass route
+                    ovf = true;
+#endif
+                    if (ovf) misc[M_OVF] = 1u;
+                    __syncthreads();
+                    if (misc[M_OVF]) {                                          // (uniform) rare: low-complexity windows
+                        __syncthreads();                                        // everybody has seen the flag
+                        for (int i = tid; i < int(L.t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
+                        if (tid == 0) misc[M_OVF] = 0u;
                         __syncthreads();
-                        k = 0;
-                        for (uint32_t e = tid; e < nb; e += NT, ++k) score_one(T, uint32_t(mine[e]), (reps >> k) & 1u, plain_c, lv_c);
+                        pass16(2 * p);
+                        pass16(2 * p + 1);
+                    } else {
+                        with_variant([&](auto plain_c, auto lv_c) {
+                            int kk = 0;
+                            for (uint32_t e = tid; e < nb; e += NT, ++kk) score_one(T8, uint32_t(mine[e]), (reps >> kk) & 1ull, plain_c, lv_c);
+                        });
                         __syncthreads();
                         k = 0;
                         for (uint32_t e = tid; e < nb; e += NT, ++k)
-                            if ((reps >> k) & 1u) t8h[uint32_t(mine[e]) & 0x3FFFu] = 0;
-                        __syncthreads();
-                    };
-                    for (int p = 0; p < 2; ++p) {
-                        const uint32_t nb = q_tot[2 * p] + q_tot[2 * p + 1];   // the two buckets are neighbours in the list
-                        const uint16_t* mine = qlist + q_start[2 * p];
-                        unsigned long long reps = 0;                            // <= 2 * ITS <= 40 entries per thread
-                        bool ovf = false;
-                        int k = 0;
-                        for (uint32_t e = tid; e < nb; e += NT, ++k) {
-                            const uint32_t idx = uint32_t(mine[e]) & 0x7FFFu;
-                            const uint32_t sh = (idx & 3u) * 8;
-                            const uint32_t old = (atomicAdd(&t8[idx >> 2], 1u << sh) >> sh) & 0xFFu;
-                            if (old == 0) reps |= 1ull << k;
-                            ovf |= (old == 255u);
-                        }
-#ifdef FRISK_Q_FORCE16      // experiment: always take the 16-bit four-pass route
-                        ovf = true;
-#endif
-                        if (ovf) misc[M_OVF] = 1u;
-                        __syncthreads();
-                        if (misc[M_OVF]) {                                      // (uniform) rare: low-complexity windows
-                            __syncthreads();                                    // everybody has seen the flag
-                            for (int i = tid; i < int(L.t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
-                            if (tid == 0) misc[M_OVF] = 0u;
-                            __syncthreads();
-                            pass16(2 * p);
-                            pass16(2 * p + 1);
-                        } else {
-                            k = 0;
-                            for (uint32_t e = tid; e < nb; e += NT, ++k) score_one(T8, uint32_t(mine[e]), (reps >> k) & 1ull, plain_c, lv_c);
-                            __syncthreads();
-                            k = 0;
-                            for (uint32_t e = tid; e < nb; e += NT, ++k)
-                                if ((reps >> k) & 1ull) t8b[uint32_t(mine[e]) & 0x7FFFu] = 0;
-                            if (p == 0) __syncthreads();    // (after the last pass the block sum's barrier does it)
-                        }
+                            if ((reps >> k) & 1ull) t8b[uint32_t(mine[e]) & 0x7FFFu] = 0;
+                        if (p == 0) __syncthreads();        // (after the last pass the block sum's barrier does it)
                     }
-                } else {
+                }
+            } else {
+                with_variant([&](auto plain_c, auto lv_c) {
 #pragma unroll
                     for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
                         // (iterations past the window are not skipped: their lanes are clamped and masked, and a
@@ -958,19 +989,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                         // 128 a 1024-thread workgroup leaves per lane, and the scheduler would spill
                         if ((it % FRISK_S4_GROUP) == FRISK_S4_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-            };
-            using orph1 = std::integral_constant<int, 1>;
-            using orph4 = std::integral_constant<int, 4>;
-            using orphN = std::integral_constant<int, 0>;
-            if (lv) {
-                if (n_orph <= 1) stage4(orph1{}, std::true_type{});
-                else if (n_orph <= 4) stage4(orph4{}, std::true_type{});
-                else stage4(orphN{}, std::true_type{});
-            } else {
-                if (n_orph <= 1) stage4(orph1{}, std::false_type{});
-                else if (n_orph <= 4) stage4(orph4{}, std::false_type{});
-                else stage4(orphN{}, std::false_type{});
+                });
             }
             exact_end(accw); exact_end(accg); exact_end(acct);
             block_sum3<NW>(accw, accg, acct, scratch_base, tid);
