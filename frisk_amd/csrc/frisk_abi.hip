@@ -75,7 +75,7 @@ struct frisk_ctx {
     DevBuf<int32_t> o_seq;
     DevBuf<int64_t> o_start, o_stop, o_meta;
     DevBuf<uint32_t> o_status, o_counts;
-    DevBuf<double> o_kld, o_gc, o_pi, o_si, o_cri;
+    DevBuf<double> o_kld, o_gc, o_pi, o_si, o_cri, o_sw, o_sg;
 };
 
 namespace {
@@ -245,7 +245,7 @@ void frisk_destroy(frisk_ctx* c) {
     c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
-    c->o_kld.release(); c->o_gc.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
+    c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -612,6 +612,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     const size_t N = size_t(n);
     HIPC(c, c->o_seq.reserve(N)); HIPC(c, c->o_start.reserve(N)); HIPC(c, c->o_stop.reserve(N));
     HIPC(c, c->o_status.reserve(N)); HIPC(c, c->o_kld.reserve(N)); HIPC(c, c->o_gc.reserve(N));
+    HIPC(c, c->o_sw.reserve(N)); HIPC(c, c->o_sg.reserve(N));
     if (rip) { HIPC(c, c->o_pi.reserve(N)); HIPC(c, c->o_si.reserve(N)); HIPC(c, c->o_cri.reserve(N)); }
     if (dbg_counts) {
         HIPC(c, c->o_counts.reserve(N * size_t(c->nprof)));
@@ -630,7 +631,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.orphan_cap = int32_t(c->plan_maxwin / 8 + 2);
     P.nprof = int32_t(c->nprof);
     P.seq_index = c->o_seq.p; P.start = c->o_start.p; P.stop = c->o_stop.p; P.status = c->o_status.p;
-    P.kld = c->o_kld.p; P.gc = c->o_gc.p;
+    P.kld = c->o_kld.p; P.gc = c->o_gc.p; P.sw = c->o_sw.p; P.sg = c->o_sg.p;
     P.pi = rip ? c->o_pi.p : nullptr; P.si = rip ? c->o_si.p : nullptr; P.cri = rip ? c->o_cri.p : nullptr;
     P.dbg_counts = dbg_counts ? c->o_counts.p : nullptr;
     P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
@@ -703,6 +704,13 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
 #undef FRISK_LAUNCH
     HIPC(c, e);
+#ifndef FRISK_STOP
+    if (c->plan_maxwin <= 65535 && n > 0) {     // the LDS kernels leave the rows' scalar tail to one thread per row
+        finish_rows_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(n, c->o_status.p, c->o_kld.p, c->o_gc.p, c->o_sw.p,
+                                                                            c->o_sg.p);
+        HIPC(c, hipGetLastError());
+    }
+#endif
     HIPC(c, hipEventRecord(c->ev1, c->stream));
 
     HIPC(c, hipMemcpyAsync(seq_index, c->o_seq.p, N * 4, hipMemcpyDeviceToHost, c->stream));

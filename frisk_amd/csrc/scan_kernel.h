@@ -63,8 +63,10 @@ struct ScanParams {
     int64_t* start;
     int64_t* stop;
     uint32_t* status;
-    double* kld;
-    double* gc;
+    double* kld;              // scan_kernel leaves T = sum Iw ln(Iw/Ig) here, finish_rows_kernel turns it into the KLD
+    double* gc;               // scan_kernel leaves {S << 32 | G+C} here, finish_rows_kernel the fraction
+    double* sw;               // raw sums of the row: sum Iw ...
+    double* sg;               // ... and sum Ig (NaN: a max-mer without genome weight)
     double* pi;
     double* si;
     double* cri;
@@ -313,7 +315,9 @@ __device__ inline double div_exact(double n, double d) {
 
 // sum three accumulators over the workgroup; every thread returns the same totals.  One barrier: the scratch is
 // rewritten only after the window's last barrier.
-template <int NW>
+// WAVE0_ONLY: only the first wave adds up the per-wave partials (the others return garbage): the caller's scalar tail -
+// two logarithms and a division - then costs one wave's instructions per window instead of every wave's.
+template <int NW, bool WAVE0_ONLY = false>
 __device__ inline void block_sum3(ExactSum& a, ExactSum& b, ExactSum& c, double* scratch, int tid) {
     for (int o = 32; o > 0; o >>= 1) {
         a.hi += __shfl_down(a.hi, o); a.lo += __shfl_down(a.lo, o);
@@ -325,6 +329,7 @@ __device__ inline void block_sum3(ExactSum& a, ExactSum& b, ExactSum& c, double*
         p[0] = a.hi; p[1] = a.lo; p[2] = b.hi; p[3] = b.lo; p[4] = c.hi; p[5] = c.lo;
     }
     __syncthreads();
+    if (WAVE0_ONLY && tid >= 64) return;
     ExactSum sa = {0.0, 0.0}, sb = {0.0, 0.0}, sc = {0.0, 0.0};
     for (int w = 0; w < NW; ++w) {
         const double* p = scratch + w * 6;
@@ -790,7 +795,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             if (nvalid_top > 0 && S >= kmin - 1 && S <= kmax - 1) status |= ROW_ZERO_WEIGHT;
             status |= ROW_KEPT;
             if (tid == 0) {
-                P.gc[row] = double(upG + upC) / double(S);                  // L136
+                // composition: numerator and denominator only - the division (L136) is finish_rows_kernel's, off this
+                // workgroup's critical path
+                P.gc[row] = __longlong_as_double((long long)((uint64_t(uint32_t(S)) << 32) | uint32_t(upG + upC)));
                 // RIP indices from the window's dinucleotide counts (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3
                 if (P.flags & 1u) {
                     const double qnan = __longlong_as_double(0x7FF8000000000000LL);
@@ -992,21 +999,44 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                 });
             }
             exact_end(accw); exact_end(accg); exact_end(acct);
+#ifdef FRISK_STOP
             block_sum3<NW>(accw, accg, acct, scratch_base, tid);
+#else
+            block_sum3<NW, true>(accw, accg, acct, scratch_base, tid);
+#endif
             zero_own_bins();                                // behind the barrier: nobody reads the max-mer table any more
-            const double Sw = exact_value(accw), Sg = exact_value(accg), Tt = exact_value(acct);
-            STOP_AFTER(4, Sw + Sg + Tt)
-            // KLD = sum Pw log2(Pw/Pg) = (T/Sw - ln Sw + ln Sg) / ln 2            (L453-454, L465-470)
-            const double LN2 = 0.69314718055994530942;
-            const double acc = (nvalid_top == 0) ? 0.0 : ((Tt / Sw - log(Sw)) + log(Sg)) / LN2;
-
             clear_small();                                  // all reads of the small tables are behind the barrier
+#ifdef FRISK_STOP
+            { const double Sw = exact_value(accw), Sg = exact_value(accg), Tt = exact_value(acct); STOP_AFTER(4, Sw + Sg + Tt) }
+#endif
+            // the scalar tail of the row - two logarithms and a division, ~2 000 cycles of dependent instructions that every
+            // other wave would wait for at the window's last barrier - is left to finish_rows_kernel (all rows in parallel)
             if (tid == 0) {
-                if (nvalid_top > 0 && Sg != Sg) status |= ROW_ZERO_WEIGHT;      // a max-mer without genome weight (L437)
                 P.status[row] = status;
-                P.kld[row] = acc;
+                P.kld[row] = exact_value(acct);
+                P.sw[row] = exact_value(accw);
+                P.sg[row] = exact_value(accg);
             }
             __syncthreads();
         }
     }
+}
+
+// Per-row scalar tail of scan_kernel: KLD = sum Pw log2(Pw/Pg) = (T/Sw - ln Sw + ln Sg) / ln 2 (L453-454, L465-470), the GC
+// fraction (L136) and the ZeroDivisionError flag of a max-mer without genome weight (L437).  Rows that were dropped by the
+// N filter keep their NaNs.
+__global__ __launch_bounds__(256) void finish_rows_kernel(int64_t n, uint32_t* __restrict__ status, double* __restrict__ kld,
+                                                           double* __restrict__ gc, const double* __restrict__ sw,
+                                                           const double* __restrict__ sg) {
+    const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    uint32_t st = status[row];
+    if (!(st & ROW_KEPT)) return;
+    const uint64_t packed = uint64_t(__double_as_longlong(gc[row]));
+    gc[row] = double(uint32_t(packed)) / double(int64_t(packed >> 32));
+    if (st & ROW_NO_MAXMER) { kld[row] = 0.0; return; }
+    const double Tt = kld[row], Sw = sw[row], Sg = sg[row];
+    const double LN2 = 0.69314718055994530942;
+    kld[row] = ((Tt / Sw - log(Sw)) + log(Sg)) / LN2;
+    if (Sg != Sg) status[row] = st | ROW_ZERO_WEIGHT;
 }
