@@ -317,13 +317,32 @@ __device__ inline double div_exact(double n, double d) {
 // rewritten only after the window's last barrier.
 // WAVE0_ONLY: only the first wave adds up the per-wave partials (the others return garbage): the caller's scalar tail -
 // two logarithms and a division - then costs one wave's instructions per window instead of every wave's.
+// x + (x of another lane of the same row of 16, chosen by a DPP control): one register move per 32-bit half
+template <int CTRL>
+__device__ inline double dpp_add(double x) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    return x + __hiloint2double(hi, lo);
+}
+
+// sum of x over the wave, valid in every lane: a butterfly inside each row of 16 lanes by DPP (quad_perm [1,0,3,2] and
+// [2,3,0,1], row_half_mirror, row_mirror), then the four row sums by v_readlane.  The additions here are exact (see
+// ExactSum), so their order is free.  (A __shfl_down tree is six dependent LDS-crossbar round trips per value.)
+__device__ inline double wave_sum_exact(double x) {
+    x = dpp_add<0xB1>(x);
+    x = dpp_add<0x4E>(x);
+    x = dpp_add<0x141>(x);
+    x = dpp_add<0x140>(x);
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    auto row = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l)); };
+    return (row(0) + row(16)) + (row(32) + row(48));
+}
+
 template <int NW, bool WAVE0_ONLY = false>
 __device__ inline void block_sum3(ExactSum& a, ExactSum& b, ExactSum& c, double* scratch, int tid) {
-    for (int o = 32; o > 0; o >>= 1) {
-        a.hi += __shfl_down(a.hi, o); a.lo += __shfl_down(a.lo, o);
-        b.hi += __shfl_down(b.hi, o); b.lo += __shfl_down(b.lo, o);
-        c.hi += __shfl_down(c.hi, o); c.lo += __shfl_down(c.lo, o);
-    }
+    a.hi = wave_sum_exact(a.hi); a.lo = wave_sum_exact(a.lo);
+    b.hi = wave_sum_exact(b.hi); b.lo = wave_sum_exact(b.lo);
+    c.hi = wave_sum_exact(c.hi); c.lo = wave_sum_exact(c.lo);
     if ((tid & 63) == 0) {
         double* p = scratch + (tid >> 6) * 6;
         p[0] = a.hi; p[1] = a.lo; p[2] = b.hi; p[3] = b.lo; p[4] = c.hi; p[5] = c.lo;
@@ -736,7 +755,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             // Lanes 0..8 of EVERY wave do the nine divisions; the other lanes read them by lane index (no barrier, no
             // LDS round trip).  Wave 0 also stores them for the paths that index r_x at run time.
             double r_lane = 0.0;
-            if (lane <= 8) r_lane = double(1u << (2 * lane)) / double(int32_t((S - (lane - 1)) * 2));
+            if (lane <= 8) r_lane = div_exact(double(1u << (2 * lane)), double(int32_t((S - (lane - 1)) * 2)));    // (the IEEE quotient
+            // for these operands; a zero divisor gives inf/NaN like the IEEE division, and the row is flagged anyway)
             if (tid <= 8) rtab[tid] = r_lane;
             auto r_of = [&](int x) -> double {                               // x: wave-uniform
                 return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r_lane), x),
