@@ -656,10 +656,13 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     const int64_t need = (c->plan_maxwin + 511) / 512;
     const int its = need <= 4 ? 4 : need <= 10 ? 10 : need <= 16 ? 16 : 0;
 
-    // quarter-table form of the K = 8 fast paths (two workgroups per CU) - FRISK_K8_ONE_WG=1 keeps the one-workgroup form
+    // quarter-table form of the K = 8 fast paths (two workgroups per CU)
     P.list_cap = int32_t((c->plan_maxwin + 7) / 8 * 8);
     const LdsLayout Lq = make_layout(c->kmin, c->kmax, P.orphan_cap, P.lv, true, P.list_cap);
-    const bool quart = k8 && c->plan_maxwin <= 5120 && Lq.total <= 80 * 1024 && !std::getenv("FRISK_K8_ONE_WG");
+    // (since the per-row tail and the wave reductions left the critical path, one 512-thread workgroup per CU is the faster
+    //  form at K = 8 again - 25.0 vs 23.6 M windows/s on the bench shard; FRISK_K8_QUART=1 selects the two-workgroup form)
+    const bool quart = k8 && c->plan_maxwin <= 5120 && Lq.total <= 80 * 1024 && std::getenv("FRISK_K8_QUART");
+    const bool force_one = std::getenv("FRISK_ONE_WG") != nullptr;      // tuning knob: never two workgroups per CU
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
     if (c->plan_maxwin > 65535) {
@@ -687,7 +690,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         else if (its == 10) FRISK_LAUNCH(512, true, 10, false);
         else if (its == 16) FRISK_LAUNCH(512, true, 16, false);
         else FRISK_LAUNCH(1024, true, 0, false);
-    } else if (!debug && c->plan_maxwin <= 5120 && L.total <= 80 * 1024) {
+    } else if (!debug && !force_one && c->plan_maxwin <= 5120 && L.total <= 80 * 1024) {
         // K <= 7: the tables of a window take < 60 KB, so TWO independent 256-thread workgroups fit a CU.  The two waves of
         // a SIMD then belong to different windows in different stages, and the LDS phases of one overlap the VALU phases of
         // the other: measured -23 % (K = 7) and -26 % (K = 6) against one 512-thread workgroup with the same code.
