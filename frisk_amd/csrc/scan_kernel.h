@@ -81,6 +81,10 @@ struct ScanParams {
 
 #pragma clang fp contract(off)
 
+#ifndef FRISK_ABL
+#define FRISK_ABL 0       // diagnostic builds (tools/ablate.py): drop one ingredient at a time; results wrong by design
+#endif
+
 // Diagnostic builds only (tools/ablate.py, -DFRISK_STOP=<n>): finish every window right after stage <n> with a
 // value that depends on the stage's results, to time the stages cumulatively.  Never in the product library.
 #ifdef FRISK_STOP
@@ -515,12 +519,20 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     const int64_t gl = g0 + (j0 < n ? j0 : 0);               // clamped: loads are unconditional
                     const int64_t wi = gl >> 4, mi = gl >> 5;
                     const int shc = 32 - int(gl & 15) * 2, shm = 32 - int(gl & 31);
+#if defined(FRISK_ABL) && (FRISK_ABL & 32)      // diagnostic: no window loads at all (fake bases, all valid)
+                    const uint32_t w0 = uint32_t(wi) * 2654435761u, w1 = w0 ^ 0x9E3779B9u, w2 = w1 * 40503u;
+#else
                     const uint32_t w0 = P.codes[wi], w1 = P.codes[wi + 1], w2 = P.codes[wi + 2];
+#endif
                     const uint32_t hi = uint32_t(((uint64_t(w0) << 32) | w1) >> shc);
                     const uint32_t lo = uint32_t(((uint64_t(w1) << 32) | w2) >> shc);
                     const uint64_t acode = (uint64_t(hi) << 32) | lo;        // bases j0 .. j0+31, first base in the top bits
+#if defined(FRISK_ABL) && (FRISK_ABL & 32)
+                    const uint32_t ainv = 0u, alow = uint32_t(mi >> 40) + uint32_t(shm >> 8);
+#else
                     const uint32_t ainv = uint32_t(((uint64_t(P.inv[mi]) << 32) | P.inv[mi + 1]) >> shm);
                     const uint32_t alow = uint32_t(((uint64_t(P.low[mi]) << 32) | P.low[mi + 1]) >> shm);
+#endif
                     auto topbits = [](int k) -> uint32_t {                  // the k most significant bits (k clamped to 0..32)
                         k = k < 0 ? 0 : (k > 32 ? 32 : k);
                         return uint32_t(0xFFFFFFFF00000000ull >> k);
