@@ -696,7 +696,53 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                                                (ch.y >> 16));
                 }
             };
-            {
+            if (K8 && kmin <= 4) {
+                // K = 8 (small tables = orders kmin..6), two phases instead of five dependent levels:
+                //   A  thread q < 256 owns the 4-mer q: its sixteen 6-mer counts give the four C_5 and C_4[q] in one go;
+                //   B  wave 0: lane l owns the 3-mer l, orders 2 and 1 follow inside the wave by DPP sums over quads and
+                //      rows of 16 lanes - no LDS round trip between the levels.
+                const uint32_t o6 = uint32_t(table_offset(kmin, 6)), o5 = uint32_t(table_offset(kmin, 5)),
+                               o4 = uint32_t(table_offset(kmin, 4));
+                if (tid < 256) {
+                    uint32_t c5[4], c4 = small16[o4 + tid];
+                    const uint2 d5 = *reinterpret_cast<const uint2*>(small16 + o5 + 4 * tid);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint2 ch = *reinterpret_cast<const uint2*>(small16 + o6 + 16 * tid + 4 * j);
+                        const uint32_t d = (j == 0) ? (d5.x & 0xFFFFu) : (j == 1) ? (d5.x >> 16) : (j == 2) ? (d5.y & 0xFFFFu) : (d5.y >> 16);
+                        c5[j] = d + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
+                        c4 += c5[j];
+                    }
+                    *reinterpret_cast<uint2*>(small16 + o5 + 4 * tid) = make_uint2(c5[0] | (c5[1] << 16), c5[2] | (c5[3] << 16));
+                    small16[o4 + tid] = uint16_t(c4);
+                }
+                __syncthreads();
+                if (kmin <= 3) {
+                    if (tid < 64) {
+                        const uint32_t o3 = uint32_t(table_offset(kmin, 3));
+                        const uint2 ch = *reinterpret_cast<const uint2*>(small16 + o4 + 4 * tid);
+                        const uint32_t c3 = small16[o3 + tid] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
+                        small16[o3 + tid] = uint16_t(c3);
+                        if (kmin <= 2) {
+                            auto dppi = [](uint32_t x, auto ctrl) { return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), decltype(ctrl)::value, 0xF, 0xF, false)); };
+                            uint32_t q = c3 + dppi(c3, std::integral_constant<int, 0xB1>{});         // quad_perm [1,0,3,2]
+                            q += dppi(q, std::integral_constant<int, 0x4E>{});                       // quad_perm [2,3,0,1]: the quad's sum
+                            const uint32_t o2 = uint32_t(table_offset(kmin, 2));
+                            uint32_t c2 = 0;
+                            if ((tid & 3) == 0) { c2 = small16[o2 + (tid >> 2)] + q; small16[o2 + (tid >> 2)] = uint16_t(c2); }
+                            if (kmin <= 1) {
+                                // c2 sits in one lane of every quad: spread it over the quad, then fold the row's four quads
+                                uint32_t row = c2 + dppi(c2, std::integral_constant<int, 0xB1>{});
+                                row += dppi(row, std::integral_constant<int, 0x4E>{});
+                                row += dppi(row, std::integral_constant<int, 0x141>{});              // row_half_mirror
+                                row += dppi(row, std::integral_constant<int, 0x140>{});              // row_mirror: the four C_2 of the row
+                                if ((tid & 15) == 0) small16[tid >> 4] = uint16_t(small16[tid >> 4] + row);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            } else {
                 int x = ks - 1;
 #ifndef FRISK_MARG_WIDE
 #define FRISK_MARG_WIDE 3
