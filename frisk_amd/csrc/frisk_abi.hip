@@ -635,6 +635,13 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.pi = rip ? c->o_pi.p : nullptr; P.si = rip ? c->o_si.p : nullptr; P.cri = rip ? c->o_cri.p : nullptr;
     P.dbg_counts = dbg_counts ? c->o_counts.p : nullptr;
     P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
+    P.stamps = nullptr;
+#ifdef FRISK_STAMPS
+    DevBuf<unsigned long long> d_stamps;
+    HIPC(c, d_stamps.reserve(4 * 16 * 12));
+    HIPC(c, hipMemsetAsync(d_stamps.p, 0, 4 * 16 * 12 * 8, c->stream));
+    P.stamps = d_stamps.p;
+#endif
 
     const bool k8 = (c->kmax == 8);
     // LDS budget: 160 KB per workgroup.  Long windows at K = 8 need a long orphan list; the shared prefix tables
@@ -707,6 +714,23 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
 #undef FRISK_LAUNCH
     HIPC(c, e);
+#ifdef FRISK_STAMPS
+    {
+        std::vector<unsigned long long> h(4 * 16 * 12);
+        HIPC(c, hipMemcpyAsync(h.data(), d_stamps.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        static const char* names[9] = {"stage1", "barrier1", "stage2", "stage3", "barrier3", "stage4", "blocksum", "cleanup+store", "endbarrier"};
+        double acc[9] = {0}; int cnt = 0;
+        for (int b = 0; b < 4; ++b) for (int w = 4; w < 16; ++w) {
+            const unsigned long long* t = &h[(b * 16 + w) * 12];
+            if (!t[0] || !t[9]) continue;
+            for (int i = 0; i < 9; ++i) acc[i] += double(t[i + 1] - t[i]);
+            ++cnt;
+        }
+        if (cnt) { std::fprintf(stderr, "[stamps] windows %d:", cnt); for (int i = 0; i < 9; ++i) std::fprintf(stderr, " %s %.0f", names[i], acc[i] / cnt); std::fprintf(stderr, "\n"); }
+        d_stamps.release();
+    }
+#endif
 #ifndef FRISK_STOP
     if (c->plan_maxwin <= 65535 && n > 0) {     // the LDS kernels leave the rows' scalar tail to one thread per row
         finish_rows_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(n, c->o_status.p, c->o_kld.p, c->o_gc.p, c->o_sw.p,

@@ -72,6 +72,7 @@ struct ScanParams {
     double* cri;
     uint32_t* dbg_counts;
     int64_t* dbg_meta;
+    unsigned long long* stamps;   // -DFRISK_STAMPS builds only: s_memtime at the stage boundaries of the first workgroups
 };
 
 #define ROW_KEPT 1u
@@ -80,6 +81,16 @@ struct ScanParams {
 #define ROW_NO_MAXMER 8u
 
 #pragma clang fp contract(off)
+
+// Diagnostic builds only (-DFRISK_STAMPS): wave 0 of the first 4 workgroups records s_memtime at up to 12 points of its first
+// 16 windows; the launcher prints the per-stage cycle differences.  Never in the product library.
+#ifdef FRISK_STAMPS
+#define STAMP(i)                                                                                          \
+    if (tid == 0 && blockIdx.x < 4 && stamp_win < 16)                                                     \
+        P.stamps[(blockIdx.x * 16 + stamp_win) * 12 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i)
+#endif
 
 #ifndef FRISK_ABL
 #define FRISK_ABL 0       // diagnostic builds (tools/ablate.py): drop one ingredient at a time; results wrong by design
@@ -416,6 +427,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
     int dsi = -1;
     uint32_t parity = 0;
+#ifdef FRISK_STAMPS
+    int stamp_win = -1;
+#endif
 
     for (int64_t q = v; q < nchunks; q += G) {
         const int64_t cb = P.c0 + q * P.chunk;
@@ -433,6 +447,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                 d = P.descs[lo];
                 dsi = lo;
             }
+#ifdef FRISK_STAMPS
+            ++stamp_win;
+#endif
             const int64_t j = cand - d.cand0;
             int64_t st;                // 0-based first base of the window inside the scaffold
             int64_t rep_start, rep_stop;   // coordinates as the reference reports them
@@ -455,6 +472,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             }
             const int64_t g0 = d.off + st;
             const int64_t row = cand - P.c0;
+            STAMP(0)
             uint32_t* misc = misc_base + parity * FRISK_MISC_SLOTS;         // this window's counters
             uint32_t* misc_other = misc_base + (parity ^ 1u) * FRISK_MISC_SLOTS;
             parity ^= 1u;
@@ -646,7 +664,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     if (nvalid) atomicAdd(&misc[M_NVALID], nvalid);
                 }
             }
+            STAMP(1)
             __syncthreads();
+            STAMP(2)
             if (tid < FRISK_MISC_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
             uint32_t q_tot[4] = {0, 0, 0, 0}, q_start[4] = {0, 0, 0, 0};   // QUART: the four buckets of the list
             if constexpr (QUART) {
@@ -762,6 +782,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     __syncthreads();
                 }
             }
+            STAMP(3)
             // window-uniform values read back from LDS are moved to scalar registers: they stay live to the end of the
             // window and must not cost a vector register (nor depend on which lanes a later loop leaves active)
             auto uni = [](uint32_t v) -> uint32_t { return __builtin_amdgcn_readfirstlane(v); };
@@ -851,7 +872,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     pre_w[c] = W;                   // < 65536 * 4^6
                 }
             }
+            STAMP(4)
             __syncthreads();
+            STAMP(5)
             STOP_AFTER(3, lv ? pre_i[tid & 1023] : rtab[1])
 
             if (DEBUG && P.dbg_counts) {
@@ -1076,12 +1099,14 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     }
                 });
             }
+            STAMP(6)
             exact_end(accw); exact_end(accg); exact_end(acct);
 #ifdef FRISK_STOP
             block_sum3<NW>(accw, accg, acct, scratch_base, tid);
 #else
             block_sum3<NW, true>(accw, accg, acct, scratch_base, tid);
 #endif
+            STAMP(7)
             zero_own_bins();                                // behind the barrier: nobody reads the max-mer table any more
             clear_small();                                  // all reads of the small tables are behind the barrier
 #ifdef FRISK_STOP
@@ -1095,7 +1120,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                 P.sw[row] = exact_value(accw);
                 P.sg[row] = exact_value(accg);
             }
+            STAMP(8)
             __syncthreads();
+            STAMP(9)
         }
     }
 }
