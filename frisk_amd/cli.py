@@ -132,6 +132,17 @@ def write_table(path, columns, rows, echo=True):
 
 
 def main(argv=None):
+    """Entry point.  A process group that this function creates is torn down before it returns."""
+    import torch.distributed as dist
+    had_group = dist.is_available() and dist.is_initialized()
+    try:
+        return _main(argv)
+    finally:
+        if not had_group and dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _main(argv=None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(funcName)s - %(message)s")
     args = mainArgs(argv)
     import torch.distributed as dist
@@ -143,6 +154,9 @@ def main(argv=None):
     if sharded and not dist.is_initialized():
         import torch
         torch.cuda.set_device(local_rank)
+        if world == 1:      # FRISK_FORCE_SHARDED outside a launcher: a one-rank rendezvous of our own
+            for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(key, val)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         print("frisk --", pp.FRISK_VERSION)
