@@ -1133,15 +1133,15 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
 __global__ __launch_bounds__(256) void finish_rows_kernel(int64_t n, uint32_t* __restrict__ status, double* __restrict__ kld,
                                                            double* __restrict__ gc, const double* __restrict__ sw,
                                                            const double* __restrict__ sg) {
-    const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (row >= n) return;
-    uint32_t st = status[row];
-    if (!(st & ROW_KEPT)) return;
-    const uint64_t packed = uint64_t(__double_as_longlong(gc[row]));
-    gc[row] = double(uint32_t(packed)) / double(int64_t(packed >> 32));
-    if (st & ROW_NO_MAXMER) { kld[row] = 0.0; return; }
-    const double Tt = kld[row], Sw = sw[row], Sg = sg[row];
-    const double LN2 = 0.69314718055994530942;
-    kld[row] = ((Tt / Sw - log(Sw)) + log(Sg)) / LN2;
-    if (Sg != Sg) status[row] = st | ROW_ZERO_WEIGHT;
+    for (int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += int64_t(gridDim.x) * blockDim.x) {
+        const uint32_t st = status[row];
+        if (!(st & ROW_KEPT)) continue;
+        const uint64_t packed = uint64_t(__double_as_longlong(gc[row]));
+        gc[row] = double(uint32_t(packed)) / double(int64_t(packed >> 32));
+        if (st & ROW_NO_MAXMER) { kld[row] = 0.0; continue; }
+        const double Tt = kld[row], Sw = sw[row], Sg = sg[row];
+        const double LN2 = 0.69314718055994530942;
+        kld[row] = ((Tt / Sw - log(Sw)) + log(Sg)) / LN2;
+        if (Sg != Sg) status[row] = st | ROW_ZERO_WEIGHT;
+    }
 }
