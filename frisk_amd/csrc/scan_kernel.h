@@ -716,8 +716,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                                                (ch.y >> 16));
                 }
             };
-            if (K8 && kmin <= 4) {
-                // K = 8 (small tables = orders kmin..6), two phases instead of five dependent levels:
+            if (ks >= 6 && kmin <= 4) {
+                for (int x = ks - 1; x >= 6; --x) {             // K = 7: its order-6 level first, all waves
+                    marg_level(x, tid, NT);
+                    __syncthreads();
+                }
+                // from order 6 down (K = 8: the small tables are orders kmin..6), two phases instead of five dependent levels:
                 //   A  thread q < 256 owns the 4-mer q: its sixteen 6-mer counts give the four C_5 and C_4[q] in one go;
                 //   B  wave 0: lane l owns the 3-mer l, orders 2 and 1 follow inside the wave by DPP sums over quads and
                 //      rows of 16 lanes - no LDS round trip between the levels.
