@@ -16,8 +16,13 @@
 #include "frisk_device.h"
 #include "profile_kernels.h"
 #include "scan_kernel.h"
+#include "scan8_kernel.h"
 #include "scan_big_kernel.h"
 #include "synth_kernel.h"
+
+#ifndef FRISK_K8_NARROW_BITS
+#define FRISK_K8_NARROW_BITS 8      // width of the order-8 counters of the default K = 8 path (scan8_kernel.h): 8, 4, or 0 = off
+#endif
 
 namespace {
 
@@ -60,7 +65,10 @@ struct frisk_ctx {
 
     // profile
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
-    DevBuf<double> d_ig, d_logtab;
+    DevBuf<double> d_ig, d_logtab, d_rctab;
+    DevBuf<int64_t> d_ovf_list;      // windows handed from scan8_kernel (narrow counters) to scan_kernel (16-bit counters)
+    DevBuf<unsigned int> d_ovf_count;
+    int64_t last_overflow = 0;       // their number in the most recent scan (diagnostic, frisk_last_scan_overflow)
     DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
     int64_t total_len = 0, ex_max = 0, nn_total = 0;
     bool profile_final = false;
@@ -171,6 +179,26 @@ hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st
     return hipGetLastError();
 }
 
+template <int NT, int ITS, int BITS, bool TABS_LDS, int WPS, bool DEBUG>
+hipError_t launch_scan8(const ScanParams& P, int grid, size_t lds, hipStream_t st) {
+    auto kern = scan8_kernel<NT, ITS, BITS, TABS_LDS, WPS, DEBUG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(lds));
+    if (e != hipSuccess) return e;
+    kern<<<grid, NT, lds, st>>>(P);
+    return hipGetLastError();
+}
+
+// Tuning knobs are read from the environment only in experiment builds (-DFRISK_TUNE); the product library has none.
+inline const char* tune_env(const char* name) {
+#ifdef FRISK_TUNE
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 int build_genome_table(frisk_ctx* c) {
     const int64_t n = int64_t(1) << (2 * c->kmax);
     const int64_t genome_space = c->total_len - c->nn_total;                    // L379
@@ -231,6 +259,12 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
         }
         HIPC(c, c->d_logtab.reserve(2 * FRISK_LOGTAB_N));
         HIPC(c, hipMemcpyAsync(c->d_logtab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
+        double rc[256];                                          // scan8_kernel.h: weight 1/c of a position whose max-mer occurs c times
+        rc[0] = 0.0;
+        for (int i = 1; i < 256; ++i) rc[i] = 1.0 / double(i);
+        HIPC(c, c->d_rctab.reserve(256));
+        HIPC(c, hipMemcpyAsync(c->d_rctab.p, rc, sizeof(rc), hipMemcpyHostToDevice, c->stream));
+        HIPC(c, c->d_ovf_count.reserve(4));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -242,7 +276,7 @@ void frisk_destroy(frisk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_ascii.release(); c->d_codes.release(); c->d_inv.release(); c->d_low.release();
-    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_big.release(); c->d_desc.release();
+    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_rctab.release(); c->d_ovf_list.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
     c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
@@ -636,6 +670,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.dbg_counts = dbg_counts ? c->o_counts.p : nullptr;
     P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
     P.stamps = nullptr;
+    P.rc_tab = c->d_rctab.p; P.ovf_list = nullptr; P.ovf_count = c->d_ovf_count.p; P.from_list = 0;
+    c->last_overflow = 0;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
     HIPC(c, d_stamps.reserve(4 * 16 * 12));
@@ -656,7 +692,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     if (grid >= 8) grid &= ~7;
     int64_t chunk = n / (int64_t(grid) * 8);
     chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, 8));     // measured: 8 is best, 1..64 within 3 %
-    if (const char* ev = std::getenv("FRISK_SCAN_CHUNK")) chunk = std::max<int64_t>(1, std::atoll(ev));   // tuning knob
+    if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk = std::max<int64_t>(1, std::atoll(ev));   // tuning knob
     P.chunk = int32_t(chunk);
     // fast paths: 512-thread workgroups, per-position loops unrolled ITS = 4 / 10 / 16 times (windows up to 2048 /
     // 5120 / 8192 bases); anything longer (up to 65535): generic 1024-thread kernel with runtime loops
@@ -668,8 +704,12 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     const LdsLayout Lq = make_layout(c->kmin, c->kmax, P.orphan_cap, P.lv, true, P.list_cap);
     // (since the per-row tail and the wave reductions left the critical path, one 512-thread workgroup per CU is the faster
     //  form at K = 8 again - 25.0 vs 23.6 M windows/s on the bench shard; FRISK_K8_QUART=1 selects the two-workgroup form)
-    const bool quart = k8 && c->plan_maxwin <= 5120 && Lq.total <= 80 * 1024 && std::getenv("FRISK_K8_QUART");
-    const bool force_one = std::getenv("FRISK_ONE_WG") != nullptr;      // tuning knob: never two workgroups per CU
+    const bool quart = k8 && c->plan_maxwin <= 5120 && Lq.total <= 80 * 1024 && tune_env("FRISK_K8_QUART");
+    const bool force_one = tune_env("FRISK_ONE_WG") != nullptr;      // tuning knob: never two workgroups per CU
+    // narrow-counter form (scan8_kernel.h): K = 8, kmin <= 5 (shared prefix level), windows of at most 256 x 20 bases
+    int narrow_bits = FRISK_K8_NARROW_BITS;
+    if (const char* ev = tune_env("FRISK_K8_BITS")) narrow_bits = std::atoi(ev);
+    const bool narrow = k8 && c->kmin <= 5 && c->plan_maxwin <= 5120 && (narrow_bits == 4 || narrow_bits == 8) && !quart;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
     if (c->plan_maxwin > 65535) {
@@ -683,7 +723,40 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         e = hipGetLastError();
     } else
 #define FRISK_LAUNCH(NT_, K8_, ITS_, DBG_) e = launch_scan<NT_, K8_, ITS_, DBG_>(P, grid, L.total, c->stream)
-    if (k8 && !debug && quart) {
+    if (narrow) {
+        // K = 8 default: narrow order-8 counters, two (8-bit) or three (4-bit) independent 256-thread workgroups per CU
+        // (scan8_kernel.h); windows whose counters wrap are appended to ovf_list and redone by the 16-bit form below
+        HIPC(c, c->d_ovf_list.reserve(N));
+        HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, sizeof(unsigned int), c->stream));
+        P.ovf_list = c->d_ovf_list.p;
+        const bool small_w = c->plan_maxwin <= 2048;
+        const int wgs = narrow_bits == 4 ? 3 : 2;
+        const Lds8 L8 = narrow_bits == 4 ? make_layout8<4>(c->kmin, true) : make_layout8<8>(c->kmin, false);
+        int g8 = int(std::min<int64_t>(n, int64_t(c->num_cu) * wgs));
+        if (g8 >= 8) g8 &= ~7;
+        ScanParams P8 = P;
+        P8.chunk = int32_t(std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(g8) * 8), 8)));
+        if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) P8.chunk = int32_t(std::max<int64_t>(1, std::atoll(ev)));
+#define FRISK_LAUNCH8(ITS_, BITS_, TL_, WPS_, DBG_) e = launch_scan8<256, ITS_, BITS_, TL_, WPS_, DBG_>(P8, g8, L8.total, c->stream)
+        if (narrow_bits == 4) {
+            if (debug) { if (small_w) FRISK_LAUNCH8(8, 4, true, 3, true); else FRISK_LAUNCH8(20, 4, true, 3, true); }
+            else if (small_w) FRISK_LAUNCH8(8, 4, true, 3, false);
+            else FRISK_LAUNCH8(20, 4, true, 3, false);
+        } else {
+            if (debug) { if (small_w) FRISK_LAUNCH8(8, 8, false, 2, true); else FRISK_LAUNCH8(20, 8, false, 2, true); }
+            else if (small_w) FRISK_LAUNCH8(8, 8, false, 2, false);
+            else FRISK_LAUNCH8(20, 8, false, 2, false);
+        }
+#undef FRISK_LAUNCH8
+        HIPC(c, e);
+        // second launch: the handed-over windows, one per workgroup at a time, 16-bit counters (a no-op when the list is empty)
+        P.from_list = 1;
+        grid = int(std::min<int64_t>(n, int64_t(c->num_cu)));
+        if (grid >= 8) grid &= ~7;
+        if (debug) FRISK_LAUNCH(512, true, 16, true);
+        else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
+        else FRISK_LAUNCH(512, true, 10, false);
+    } else if (k8 && !debug && quart) {
         // K = 8 with TWO independent 256-thread workgroups per CU: the order-8 table serves one leading base at a time
         // (32 KiB), the window's max-mers are bucketed by leading base and handled in four passes (scan_kernel.h, QUART)
         grid = int(std::min<int64_t>(n, int64_t(c->num_cu) * 2));
@@ -754,11 +827,16 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     if (dbg_counts)
         HIPC(c, hipMemcpyAsync(dbg_counts, c->o_counts.p, N * size_t(c->nprof) * 4, hipMemcpyDeviceToHost, c->stream));
     if (dbg_meta) HIPC(c, hipMemcpyAsync(dbg_meta, c->o_meta.p, N * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned int novf = 0;
+    if (narrow) HIPC(c, hipMemcpyAsync(&novf, c->d_ovf_count.p, sizeof(novf), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    c->last_overflow = novf;
     float ms = 0;
     HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->ms[0] = ms;
     return FRISK_OK;
 }
+
+int64_t frisk_last_scan_overflow(const frisk_ctx* c) { return c ? c->last_overflow : -1; }
 
 }  // extern "C"

@@ -73,6 +73,11 @@ struct ScanParams {
     uint32_t* dbg_counts;
     int64_t* dbg_meta;
     unsigned long long* stamps;   // -DFRISK_STAMPS builds only: s_memtime at the stage boundaries of the first workgroups
+    // hand-over from scan8_kernel.h (narrow order-8 counters) to this file's 16-bit form: windows whose counters wrapped
+    const double* rc_tab;         // 1/c for c = 0..255 (entry 0 = 0): the weight of one of the c positions that share a max-mer
+    int64_t* ovf_list;            // candidate indices appended by scan8_kernel ...
+    unsigned int* ovf_count;      // ... and their number
+    int32_t from_list;            // != 0: scan_kernel takes its candidates from ovf_list[0 .. *ovf_count) instead of [c0, c1)
 };
 
 #define ROW_KEPT 1u
@@ -420,8 +425,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     const int G = gridDim.x;
     int v = blockIdx.x;
     if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int64_t ncand = P.c1 - P.c0;
-    const int64_t nchunks = (ncand + P.chunk - 1) / P.chunk;
+    // candidates: the range [c0, c1) in chunks, or (from_list) the windows that scan8_kernel handed over, one at a time
+    const bool listed = P.from_list != 0;
+    const int64_t ncand = listed ? int64_t(*P.ovf_count) : P.c1 - P.c0;
+    const int64_t chunk = listed ? 1 : P.chunk;
+    const int64_t nchunks = (ncand + chunk - 1) / chunk;
 
     ScafDesc d;
     d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
@@ -432,9 +440,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
 #endif
 
     for (int64_t q = v; q < nchunks; q += G) {
-        const int64_t cb = P.c0 + q * P.chunk;
-        const int64_t ce = (cb + P.chunk < P.c1) ? cb + P.chunk : P.c1;
-        for (int64_t cand = cb; cand < ce; ++cand) {
+        const int64_t cb = listed ? q : P.c0 + q * chunk;
+        const int64_t ce = listed ? q + 1 : ((cb + chunk < P.c1) ? cb + chunk : P.c1);
+        for (int64_t ci = cb; ci < ce; ++ci) {
+            const int64_t cand = listed ? P.ovf_list[ci] : ci;
             // ---- which scaffold / window is this candidate? (uniform across the workgroup)
             if (cand < d.cand0 || cand >= d.cand0 + d.ncand) {
                 int lo = 0, hi = P.n_desc - 1;

@@ -125,6 +125,11 @@ int frisk_scan(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int64_t c
                double* kld, double* gc, double* pi, double* si, double* cri,
                uint32_t* dbg_counts, int64_t* dbg_meta);
 
+/* Diagnostic: how many windows of the most recent frisk_scan were redone with 16-bit counters because one of their
+ * 8-mers occurred more often than the narrow counters of the default K = 8 kernel hold (low-complexity sequence).
+ * Results do not depend on it. */
+int64_t frisk_last_scan_overflow(const frisk_ctx* ctx);
+
 /* Page-locked host memory for result buffers: D2H copies into it are asynchronous and run at PCIe rate
  * (pageable buffers work too, at a fraction of it).  Free with frisk_host_free before frisk_destroy. */
 void* frisk_host_alloc(frisk_ctx* ctx, int64_t bytes);
