@@ -20,8 +20,8 @@
 #include "scan_big_kernel.h"
 #include "synth_kernel.h"
 
-#ifndef FRISK_K8_NARROW_BITS
-#define FRISK_K8_NARROW_BITS 8      // width of the order-8 counters of the default K = 8 path (scan8_kernel.h): 8, 4, or 0 = off
+#ifndef FRISK_K8_WIDTH
+#define FRISK_K8_WIDTH 0            // order-8 counters of the default K = 8 path (scan8_kernel.h): 0 = adaptive 4/8 bits, 4, 8, 16 = off
 #endif
 
 namespace {
@@ -65,10 +65,10 @@ struct frisk_ctx {
 
     // profile
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
-    DevBuf<double> d_ig, d_logtab, d_rctab;
-    DevBuf<int64_t> d_ovf_list;      // windows handed from scan8_kernel (narrow counters) to scan_kernel (16-bit counters)
-    DevBuf<unsigned int> d_ovf_count;
-    int64_t last_overflow = 0;       // their number in the most recent scan (diagnostic, frisk_last_scan_overflow)
+    DevBuf<double> d_ig, d_logtab, d_logtab64, d_logtab32, d_rctab;
+    DevBuf<int64_t> d_ovf_list, d_ovf_list2;   // windows handed from 4-bit to 8-bit counters, and from there to the 16-bit form
+    DevBuf<unsigned int> d_ovf_count;          // [0], [1]: their numbers
+    int64_t scan_stat[3] = {0, 0, 0};          // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16
     DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
     int64_t total_len = 0, ex_max = 0, nn_total = 0;
     bool profile_final = false;
@@ -179,14 +179,28 @@ hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st
     return hipGetLastError();
 }
 
-template <int NT, int ITS, int BITS, bool TABS_LDS, int WPS, bool DEBUG>
-hipError_t launch_scan8(const ScanParams& P, int grid, size_t lds, hipStream_t st) {
-    auto kern = scan8_kernel<NT, ITS, BITS, TABS_LDS, WPS, DEBUG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       int(lds));
-    if (e != hipSuccess) return e;
-    kern<<<grid, NT, lds, st>>>(P);
+template <int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
+hipError_t launch_scan8(const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
+    constexpr int wg_per_cu = WPS * 256 / NT;
+    static_assert(Lds8<BITS, LOGN, NT>::total * wg_per_cu <= 160 * 1024, "the workgroups meant to share a CU must fit its LDS");
+    int grid = int(std::max<int64_t>(1, std::min<int64_t>(work_items, int64_t(num_cu) * wg_per_cu)));
+    if (grid >= 8) grid &= ~7;
+    scan8_kernel<NT, ITS, BITS, LOGN, WPS, DEBUG><<<grid, NT, 0, st>>>(P);      // LDS is static (Lds8)
     return hipGetLastError();
+}
+
+// one launch of the narrow-counter K = 8 kernel: counter width, window class (<= 2048 / <= 5120 bases), debug dump
+hipError_t launch_narrow(int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
+#define FRISK_L8(ITS_, BITS_, WPS_, DBG_) return launch_scan8<256, ITS_, BITS_, 64, WPS_, DBG_>(P, num_cu, work_items, st)
+    if (bits == 4) {
+        if (debug) { if (small_w) FRISK_L8(8, 4, 3, true); else FRISK_L8(20, 4, 3, true); }
+        if (small_w) FRISK_L8(8, 4, 3, false);
+        FRISK_L8(20, 4, 3, false);
+    }
+    if (debug) { if (small_w) FRISK_L8(8, 8, 2, true); else FRISK_L8(20, 8, 2, true); }
+    if (small_w) FRISK_L8(8, 8, 2, false);
+    FRISK_L8(20, 8, 2, false);
+#undef FRISK_L8
 }
 
 // Tuning knobs are read from the environment only in experiment builds (-DFRISK_TUNE); the product library has none.
@@ -251,14 +265,18 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
     HIPC(c, hipMemsetAsync(c->d_raw.p, 0, (size_t(c->nprof) + 4) * sizeof(int64_t), c->stream));
     {   // range-reduction table of the scan kernel's logarithm (scan_kernel.h: log_tab_pos)
         double tab[2 * FRISK_LOGTAB_N];
-        for (int i = 0; i < FRISK_LOGTAB_N; ++i) {
-            const double ci = 0.5 + (double(i) + 0.5) / (2.0 * FRISK_LOGTAB_N);
-            const double u = 1.0 / ci;
-            tab[2 * i] = u;
-            tab[2 * i + 1] = double(-logl((long double)u));      // -ln of the ROUNDED reciprocal: the identity stays exact
+        for (int nbin : {FRISK_LOGTAB_N, 64, 32}) {
+            for (int i = 0; i < nbin; ++i) {
+                const double ci = 0.5 + (double(i) + 0.5) / (2.0 * nbin);
+                const double u = 1.0 / ci;
+                tab[2 * i] = u;
+                tab[2 * i + 1] = double(-logl((long double)u));      // -ln of the ROUNDED reciprocal: the identity stays exact
+            }
+            DevBuf<double>& dst = nbin == 64 ? c->d_logtab64 : (nbin == 32 ? c->d_logtab32 : c->d_logtab);
+            HIPC(c, dst.reserve(2 * size_t(nbin)));
+            HIPC(c, hipMemcpyAsync(dst.p, tab, 2 * size_t(nbin) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));                // `tab` is reused
         }
-        HIPC(c, c->d_logtab.reserve(2 * FRISK_LOGTAB_N));
-        HIPC(c, hipMemcpyAsync(c->d_logtab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
         double rc[256];                                          // scan8_kernel.h: weight 1/c of a position whose max-mer occurs c times
         rc[0] = 0.0;
         for (int i = 1; i < 256; ++i) rc[i] = 1.0 / double(i);
@@ -276,7 +294,7 @@ void frisk_destroy(frisk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_ascii.release(); c->d_codes.release(); c->d_inv.release(); c->d_low.release();
-    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_rctab.release(); c->d_ovf_list.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
+    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_logtab64.release(); c->d_logtab32.release(); c->d_rctab.release(); c->d_ovf_list.release(); c->d_ovf_list2.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
     c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
@@ -659,7 +677,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
 
     ScanParams P;
     P.codes = c->d_codes.p; P.inv = c->d_inv.p; P.low = c->d_low.p;
-    P.descs = c->d_desc.p; P.ig = c->d_ig.p; P.log_tab = c->d_logtab.p;
+    P.descs = c->d_desc.p; P.ig = c->d_ig.p; P.log_tab = c->d_logtab.p; P.log_tab64 = c->d_logtab64.p; P.log_tab32 = c->d_logtab32.p;
     P.n_desc = c->n_seq + 1;
     P.kmin = c->kmin; P.kmax = c->kmax; P.w = w; P.inc = inc; P.flags = flags; P.c0 = c0; P.c1 = c1;
     P.orphan_cap = int32_t(c->plan_maxwin / 8 + 2);
@@ -670,8 +688,9 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.dbg_counts = dbg_counts ? c->o_counts.p : nullptr;
     P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
     P.stamps = nullptr;
-    P.rc_tab = c->d_rctab.p; P.ovf_list = nullptr; P.ovf_count = c->d_ovf_count.p; P.from_list = 0;
-    c->last_overflow = 0;
+    P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
+    P.sel_mode = 0; P.sel_mod = 16;
+    c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
     HIPC(c, d_stamps.reserve(4 * 16 * 12));
@@ -706,10 +725,11 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     //  form at K = 8 again - 25.0 vs 23.6 M windows/s on the bench shard; FRISK_K8_QUART=1 selects the two-workgroup form)
     const bool quart = k8 && c->plan_maxwin <= 5120 && Lq.total <= 80 * 1024 && tune_env("FRISK_K8_QUART");
     const bool force_one = tune_env("FRISK_ONE_WG") != nullptr;      // tuning knob: never two workgroups per CU
-    // narrow-counter form (scan8_kernel.h): K = 8, kmin <= 5 (shared prefix level), windows of at most 256 x 20 bases
-    int narrow_bits = FRISK_K8_NARROW_BITS;
-    if (const char* ev = tune_env("FRISK_K8_BITS")) narrow_bits = std::atoi(ev);
-    const bool narrow = k8 && c->kmin <= 5 && c->plan_maxwin <= 5120 && (narrow_bits == 4 || narrow_bits == 8) && !quart;
+    // narrow-counter form (scan8_kernel.h): K = 8, kmin <= 5 (shared prefix level), windows of at most 256 x 20 bases.
+    // width 0 = adaptive (the default), 4 / 8 = fixed, anything else = off (scan_kernel.h's 16-bit form for everything)
+    int width = FRISK_K8_WIDTH;
+    if (const char* ev = tune_env("FRISK_K8_BITS")) width = std::atoi(ev);
+    const bool narrow = k8 && c->kmin <= 5 && c->plan_maxwin <= 5120 && (width == 0 || width == 4 || width == 8) && !quart;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
     if (c->plan_maxwin > 65535) {
@@ -724,33 +744,50 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     } else
 #define FRISK_LAUNCH(NT_, K8_, ITS_, DBG_) e = launch_scan<NT_, K8_, ITS_, DBG_>(P, grid, L.total, c->stream)
     if (narrow) {
-        // K = 8 default: narrow order-8 counters, two (8-bit) or three (4-bit) independent 256-thread workgroups per CU
-        // (scan8_kernel.h); windows whose counters wrap are appended to ovf_list and redone by the 16-bit form below
+        // K = 8 default (scan8_kernel.h): narrow order-8 counters, three (4-bit) or two (8-bit) independent 256-thread
+        // workgroups per CU.  A window with a max-mer that occurs 16+ (256+) times - poly-A, microsatellites, satellite arrays -
+        // wraps a 4-bit (8-bit) counter; the kernel notices and hands it to the next wider form through a device-side list:
+        //     4-bit bulk -> list 1 -> 8-bit -> list 2 -> 16-bit (scan_kernel.h)        or        8-bit bulk -> list 2 -> 16-bit.
+        // Which width suits the bulk depends on the sequence, so (width 0) every 16th chunk of 8 windows is scanned with 4-bit
+        // counters first, and the share of it that had to be handed on decides the width for the other fifteen.  All three
+        // forms give the same bits for a window (same arithmetic; 16-bit only ever sees the windows that wrap 8 bits), so
+        // results do not depend on the choice, on the grid, or on the candidate range.
         HIPC(c, c->d_ovf_list.reserve(N));
-        HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, sizeof(unsigned int), c->stream));
-        P.ovf_list = c->d_ovf_list.p;
+        HIPC(c, c->d_ovf_list2.reserve(N));
+        HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 4 * sizeof(unsigned int), c->stream));
         const bool small_w = c->plan_maxwin <= 2048;
-        const int wgs = narrow_bits == 4 ? 3 : 2;
-        const Lds8 L8 = narrow_bits == 4 ? make_layout8<4>(c->kmin, true) : make_layout8<8>(c->kmin, false);
-        int g8 = int(std::min<int64_t>(n, int64_t(c->num_cu) * wgs));
-        if (g8 >= 8) g8 &= ~7;
-        ScanParams P8 = P;
-        P8.chunk = int32_t(std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(g8) * 8), 8)));
-        if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) P8.chunk = int32_t(std::max<int64_t>(1, std::atoll(ev)));
-#define FRISK_LAUNCH8(ITS_, BITS_, TL_, WPS_, DBG_) e = launch_scan8<256, ITS_, BITS_, TL_, WPS_, DBG_>(P8, g8, L8.total, c->stream)
-        if (narrow_bits == 4) {
-            if (debug) { if (small_w) FRISK_LAUNCH8(8, 4, true, 3, true); else FRISK_LAUNCH8(20, 4, true, 3, true); }
-            else if (small_w) FRISK_LAUNCH8(8, 4, true, 3, false);
-            else FRISK_LAUNCH8(20, 4, true, 3, false);
-        } else {
-            if (debug) { if (small_w) FRISK_LAUNCH8(8, 8, false, 2, true); else FRISK_LAUNCH8(20, 8, false, 2, true); }
-            else if (small_w) FRISK_LAUNCH8(8, 8, false, 2, false);
-            else FRISK_LAUNCH8(20, 8, false, 2, false);
+        int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), 8));
+        if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk8 = std::max<int64_t>(1, std::atoll(ev));
+        const int64_t nchunks = (n + chunk8 - 1) / chunk8;
+        ScanParams B = P;                       // the bulk launch over [c0, c1)
+        B.chunk = int32_t(chunk8);
+        int bulk = (width == 4) ? 4 : 8;
+        if (width == 0 && !debug && nchunks >= 64 * B.sel_mod) {
+            ScanParams S = B;                   // the sample
+            S.sel_mode = 1; S.out_list = c->d_ovf_list.p; S.out_count = c->d_ovf_count.p;
+            const int64_t nsample = (nchunks + S.sel_mod - 1) / S.sel_mod;
+            HIPC(c, launch_narrow(4, small_w, false, S, c->num_cu, nsample, c->stream));
+            unsigned int handed = 0;
+            HIPC(c, hipMemcpyAsync(&handed, c->d_ovf_count.p, sizeof(handed), hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            // 4-bit pays while fewer than about one window in five has to be redone (measured: 21.6 ns per window with
+            // 4-bit counters, 27.5 ns with 8-bit; redoing costs another 27.5)
+            bulk = (double(handed) <= 0.2 * double(nsample * chunk8)) ? 4 : 8;
+            B.sel_mode = 2;
         }
-#undef FRISK_LAUNCH8
-        HIPC(c, e);
-        // second launch: the handed-over windows, one per workgroup at a time, 16-bit counters (a no-op when the list is empty)
-        P.from_list = 1;
+        if (bulk == 4) { B.out_list = c->d_ovf_list.p; B.out_count = c->d_ovf_count.p; }
+        else { B.out_list = c->d_ovf_list2.p; B.out_count = c->d_ovf_count.p + 1; }
+        const int64_t bulk_chunks = B.sel_mode == 2 ? nchunks - (nchunks + B.sel_mod - 1) / B.sel_mod : nchunks;
+        HIPC(c, launch_narrow(bulk, small_w, debug, B, c->num_cu, bulk_chunks, c->stream));
+        c->scan_stat[0] = bulk;
+        if (bulk == 4 || B.sel_mode == 2) {     // list 1 (4-bit hand-overs, the sample's included) -> 8-bit -> list 2
+            ScanParams H = P;
+            H.in_list = c->d_ovf_list.p; H.in_count = c->d_ovf_count.p;
+            H.out_list = c->d_ovf_list2.p; H.out_count = c->d_ovf_count.p + 1;
+            HIPC(c, launch_narrow(8, small_w, debug, H, c->num_cu, n, c->stream));
+        }
+        // list 2 -> 16-bit counters, one window per workgroup at a time (a no-op when the list is empty)
+        P.in_list = c->d_ovf_list2.p; P.in_count = c->d_ovf_count.p + 1;
         grid = int(std::min<int64_t>(n, int64_t(c->num_cu)));
         if (grid >= 8) grid &= ~7;
         if (debug) FRISK_LAUNCH(512, true, 16, true);
@@ -827,16 +864,17 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     if (dbg_counts)
         HIPC(c, hipMemcpyAsync(dbg_counts, c->o_counts.p, N * size_t(c->nprof) * 4, hipMemcpyDeviceToHost, c->stream));
     if (dbg_meta) HIPC(c, hipMemcpyAsync(dbg_meta, c->o_meta.p, N * 3 * 8, hipMemcpyDeviceToHost, c->stream));
-    unsigned int novf = 0;
-    if (narrow) HIPC(c, hipMemcpyAsync(&novf, c->d_ovf_count.p, sizeof(novf), hipMemcpyDeviceToHost, c->stream));
+    unsigned int novf[2] = {0, 0};
+    if (narrow) HIPC(c, hipMemcpyAsync(novf, c->d_ovf_count.p, sizeof(novf), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    c->last_overflow = novf;
+    c->scan_stat[1] = novf[0];
+    c->scan_stat[2] = novf[1];
     float ms = 0;
     HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->ms[0] = ms;
     return FRISK_OK;
 }
 
-int64_t frisk_last_scan_overflow(const frisk_ctx* c) { return c ? c->last_overflow : -1; }
+int64_t frisk_last_scan_stat(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 3) ? c->scan_stat[which] : -1; }
 
 }  // extern "C"

@@ -26,35 +26,47 @@
 #pragma once
 #include "scan_kernel.h"
 
-#define FRISK8_ORPH_CAP 192        // orphan entries kept in LDS; a window with more goes to the 16-bit form
-#define FRISK8_MISC_BYTES (2 * FRISK_MISC_SLOTS * 4 + 16 * 3 * 8)
+#define FRISK8_ORPH_CAP 24         // orphan entries kept in LDS (two per invalid run); a window with more goes to the 16-bit form
+#ifndef FRISK8_UNROLL1
+#define FRISK8_UNROLL1 2           // unroll factor of the stage-1 position loop
+#endif
+#define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
 enum { M8_TSUM = 6 };              // misc slot: grand total of the order-8 table (overflow check)
 
+// LDS carve-up, all compile-time: the kernels declare it as ONE static array, so every table address is a constant that
+// folds into the 16-bit offset field of the ds_ instructions (a dynamic `extern __shared__` base costs one VALU add per
+// address).  The 32 / 64 KiB order-8 table comes LAST: its own offset is then the only large one, and it is an immediate.
+template <int BITS, int LOGN, int NT>
 struct Lds8 {
-    uint32_t t8, t8_bytes;      // order-8 table, BITS per counter
-    uint32_t small, small_bytes;   // orders kmin..5, u16 bins
-    uint32_t orphans;           // u16[FRISK8_ORPH_CAP]: run-7 positions store their 7-mer, run-6 positions 0x8000 | 6-mer << 2
-    uint32_t pre_i, pre_w;      // shared prefix tables (level 5), as in scan_kernel.h
-    uint32_t logtab, rctab;     // {1/c_i, ln c_i} x FRISK_LOGTAB_N and 1/c for c < 2^BITS - only when held in LDS
-    uint32_t misc;
-    uint32_t total;
+    static constexpr uint32_t small = 0;
+    static constexpr uint32_t small_bytes = 2736;                                  // orders kmin..5 as u16 bins, sized for kmin = 1
+    static constexpr uint32_t orphans = small + small_bytes;                       // u16[FRISK8_ORPH_CAP]
+    static constexpr uint32_t pre_i = (orphans + FRISK8_ORPH_CAP * 2 + 15) / 16 * 16;   // f64[1024]: shared prefix (level 5) ...
+    static constexpr uint32_t pre_w = pre_i + 1024 * 8;                            // ... and u32[1024], as in scan_kernel.h
+    static constexpr uint32_t logtab = pre_w + 1024 * 4;                           // {1/c_i, -ln(1/c_i)} x LOGN
+    static constexpr uint32_t rctab = logtab + uint32_t(LOGN) * 16;                // 1/c for c < 16
+    static constexpr uint32_t misc = rctab + 16 * 8;                               // counters x2, then one {Sw, Sg, T} per wave
+    static constexpr uint32_t t8 = (misc + 2 * FRISK8_SLOTS * 4 + uint32_t(NT / 64) * 3 * 8 + 15) / 16 * 16;
+    static constexpr uint32_t t8_bytes = 65536u * BITS / 8;
+    static constexpr uint32_t total = t8 + t8_bytes;
 };
 
-template <int BITS>
-__host__ __device__ inline Lds8 make_layout8(int kmin, bool tabs_lds) {
-    Lds8 L;
-    uint32_t o = 0;
-    L.t8 = o; L.t8_bytes = 65536u * BITS / 8; o += L.t8_bytes;
-    L.small = o; L.small_bytes = uint32_t((table_offset(kmin, 6) * 2 + 15) / 16 * 16); o += L.small_bytes;
-    L.orphans = o; o += FRISK8_ORPH_CAP * 2;
-    L.pre_i = o; o += 1024 * 8;
-    L.pre_w = o; o += 1024 * 4;
-    L.logtab = o; if (tabs_lds) o += FRISK_LOGTAB_N * 16;
-    L.rctab = o; if (tabs_lds) o += (1u << BITS) * 8;
-    L.misc = o; o += FRISK8_MISC_BYTES;
-    L.total = (o + 15) / 16 * 16;
-    return L;
+// ln(x), x positive and normal, by table range reduction as scan_kernel.h's log_tab_pos: x = m 2^k, m in [0.5, 1); the top
+// log2(N) mantissa bits pick the bin, tab[i] = {u_i = 1/c_i rounded, -ln u_i}, r = m u_i - 1 exactly (one fma),
+// ln x = k ln2 - ln u_i + log1p(r) with log1p by its Taylor polynomial of degree DEG.  Absolute error < 1e-15 for the ratios
+// of probabilities scored here (|k| small): what the sum T = sum Iw ln(Iw/Ig) needs.  DEG + 5 instructions.
+template <int N, int DEG>
+__device__ inline double log_tab_n(double x, const double2* tab) {
+    const int k = __builtin_amdgcn_frexp_exp(x);
+    const double m = __builtin_amdgcn_frexp_mant(x);
+    const uint32_t i = (uint32_t(__double2hiint(m)) >> (N == 128 ? 13 : (N == 64 ? 14 : 15))) & uint32_t(N - 1);
+    const double2 e = tab[i];
+    const double r = __builtin_fma(m, e.x, -1.0);
+    double p = (DEG & 1) ? 1.0 / DEG : -1.0 / DEG;
+#pragma unroll
+    for (int d = DEG - 1; d >= 2; --d) p = __builtin_fma(r, p, (d & 1) ? 1.0 / d : -1.0 / d);
+    return __builtin_fma(double(k), 0.69314718055994530942, e.y) + __builtin_fma(r * r, p, r);
 }
 
 template <int CTRL>
@@ -68,48 +80,46 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
            __builtin_amdgcn_readlane(int(x), 32) + __builtin_amdgcn_readlane(int(x), 48);
 }
 
-// NT threads, windows of at most NT*ITS bases, BITS per order-8 counter, TABS_LDS: logarithm / reciprocal tables in LDS
-// (otherwise read through the vector cache), WPS: waves per SIMD the register allocation must allow (= workgroups per
+// NT threads, windows of at most NT*ITS bases, BITS per order-8 counter, LOGN: bins of the logarithm table, WPS: waves per SIMD the register allocation must allow (= workgroups per
 // CU * NT / 256).
-template <int NT, int ITS, int BITS, bool TABS_LDS, int WPS, bool DEBUG>
+template <int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
 __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     static_assert(BITS == 4 || BITS == 8, "order-8 counters are 4 or 8 bits wide");
+    static_assert(LOGN == 32 || LOGN == 64 || LOGN == 128, "logarithm table of 32, 64 or 128 bins");
+    constexpr int LOGDEG = LOGN == 128 ? 5 : (LOGN == 64 ? 6 : 7);   // |r| < 2^-8 / 2^-7 / 2^-6: truncation r^(DEG+1)/(DEG+1) < 6e-16
     static_assert(ITS + 7 <= 32, "a lane's positions and their max-mers must fit the 32 bases it loads");
     constexpr int NW = NT / 64;
     constexpr int SHW = BITS == 8 ? 2 : 3;               // code >> SHW = dword of the table
     constexpr uint32_t PERM = (32 / BITS) - 1;           // code & PERM = field inside the dword
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int kmin = P.kmin;
-    const Lds8 L = make_layout8<BITS>(kmin, TABS_LDS);
-    uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L.t8);
-    const unsigned char* t8b = lds + L.t8;
-    uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
-    uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L.small);
-    uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L.orphans);
-    double* pre_i = reinterpret_cast<double*>(lds + L.pre_i);
-    uint32_t* pre_w = reinterpret_cast<uint32_t*>(lds + L.pre_w);
-    uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L.misc);
-    double* scratch = reinterpret_cast<double*>(lds + L.misc + 2 * FRISK_MISC_SLOTS * 4);
-    const double2* logtab = TABS_LDS ? reinterpret_cast<const double2*>(lds + L.logtab)
-                                     : reinterpret_cast<const double2*>(P.log_tab);
-    const double* rctab = TABS_LDS ? reinterpret_cast<const double*>(lds + L.rctab) : P.rc_tab;
+    using L = Lds8<BITS, LOGN, NT>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L::total];
+    const int tid0 = threadIdx.x;
+    const int kmin0 = P.kmin;
+    uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L::t8);
+    const unsigned char* t8b = lds + L::t8;
+    uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L::small);
+    uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L::small);
+    uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L::orphans);
+    double* pre_i = reinterpret_cast<double*>(lds + L::pre_i);
+    uint32_t* pre_w = reinterpret_cast<uint32_t*>(lds + L::pre_w);
+    uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L::misc);
+    double* scratch = reinterpret_cast<double*>(lds + L::misc + 2 * FRISK8_SLOTS * 4);
+    const double2* logtab = reinterpret_cast<const double2*>(lds + L::logtab);
+    const double* rctab = reinterpret_cast<const double*>(lds + L::rctab);
 
     auto clear_t8 = [&]() {
-        for (int i = tid; i < int(L.t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid0; i < int(L::t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
     };
     auto clear_small = [&]() {
-        for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid0; i < L::small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
     };
     clear_t8();
     clear_small();
-    if (tid < 2 * FRISK_MISC_SLOTS) misc_base[tid] = 0;
-    if (TABS_LDS) {
-        double2* lt = reinterpret_cast<double2*>(lds + L.logtab);
-        double* rt = reinterpret_cast<double*>(lds + L.rctab);
-        for (int i = tid; i < FRISK_LOGTAB_N; i += NT) lt[i] = reinterpret_cast<const double2*>(P.log_tab)[i];
-        for (int i = tid; i < (1 << BITS); i += NT) rt[i] = P.rc_tab[i];
+    if (tid0 < 2 * FRISK8_SLOTS) misc_base[tid0] = 0;
+    {
+        double2* lt = reinterpret_cast<double2*>(lds + L::logtab);
+        for (int i = tid0; i < LOGN; i += NT) lt[i] = reinterpret_cast<const double2*>(LOGN == 128 ? P.log_tab : (LOGN == 64 ? P.log_tab64 : P.log_tab32))[i];
+        if (tid0 < 16) reinterpret_cast<double*>(lds + L::rctab)[tid0] = P.rc_tab[tid0];
     }
     __syncthreads();
 
@@ -117,8 +127,14 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     const int G = gridDim.x;
     int v = blockIdx.x;
     if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int64_t ncand = P.c1 - P.c0;
-    const int64_t nchunks = (ncand + P.chunk - 1) / P.chunk;
+    // Which candidates: the chunks of [c0, c1) - all of them (sel_mode 0), every sel_mod-th (1: the sample that decides the
+    // counter width for the rest), all but those (2) - or, one at a time, the windows a narrower form handed over (in_list).
+    const bool listed = P.in_list != nullptr;
+    const int64_t chunk = listed ? 1 : P.chunk;
+    const int64_t nall = listed ? int64_t(*P.in_count) : (P.c1 - P.c0 + chunk - 1) / chunk;
+    const int64_t M = P.sel_mod;
+    const int64_t nsample = (nall + M - 1) / M;
+    const int64_t nchunks = listed || P.sel_mode == 0 ? nall : (P.sel_mode == 1 ? nsample : nall - nsample);
 
     ScafDesc d;
     d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
@@ -126,9 +142,13 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     uint32_t parity = 0;
 
     for (int64_t q = v; q < nchunks; q += G) {
-        const int64_t cb = P.c0 + q * P.chunk;
-        const int64_t ce = (cb + P.chunk < P.c1) ? cb + P.chunk : P.c1;
-        for (int64_t cand = cb; cand < ce; ++cand) {
+        int64_t qq = q;                                                  // chunk index inside [c0, c1)
+        if (!listed && P.sel_mode == 1) qq = q * M;
+        if (!listed && P.sel_mode == 2) qq = (q / (M - 1)) * M + 1 + q % (M - 1);
+        const int64_t cb = listed ? q : P.c0 + qq * chunk;
+        const int64_t ce = listed ? q + 1 : ((cb + chunk < P.c1) ? cb + chunk : P.c1);
+        for (int64_t ci = cb; ci < ce; ++ci) {
+            const int64_t cand = listed ? P.in_list[ci] : ci;
             // ---- which scaffold / window is this candidate? (uniform; crawlGenome L194-251)
             if (cand < d.cand0 || cand >= d.cand0 + d.ncand) {
                 int lo = 0, hi = P.n_desc - 1;
@@ -139,6 +159,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 d = P.descs[lo];
                 dsi = lo;
             }
+            // The thread index and the lowest order, opaque to the optimiser from here on: otherwise it hoists every
+            // per-position constant that depends on them (20 x {tid*20+it, masks, table offsets}: > 100 registers and
+            // dozens of spilled scalars) out of the window loop and keeps them alive across all stages.
+            int tid = tid0, kmin = kmin0;
+            asm volatile("" : "+v"(tid), "+s"(kmin));
+            const int lane = tid & 63;
             const int64_t j = cand - d.cand0;
             int64_t st, rep_start, rep_stop;
             int n;
@@ -158,8 +184,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             const int64_t g0 = d.off + st;
             const int64_t row = cand - P.c0;
-            uint32_t* misc = misc_base + parity * FRISK_MISC_SLOTS;
-            uint32_t* misc_other = misc_base + (parity ^ 1u) * FRISK_MISC_SLOTS;
+            uint32_t* misc = misc_base + parity * FRISK8_SLOTS;
+            uint32_t* misc_other = misc_base + (parity ^ 1u) * FRISK8_SLOTS;
             parity ^= 1u;
 
             // ---- stage 1: one pass over the window's positions (a lane owns ITS consecutive ones) -----------
@@ -194,7 +220,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     cG += __popcll(__ballot(sel && c2 == 2));
                     cC += __popcll(__ballot(sel && c2 == 3));
                 };
-#pragma unroll
+#pragma unroll FRISK8_UNROLL1
                 for (int it = 0; it < ITS; ++it) {
                     const uint32_t bit = 0x80000000u >> it;
                     const uint32_t c16 = code_at(it);
@@ -224,12 +250,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 for (int b = 0; (1 << b) <= ITS; ++b) nvalid += uint32_t(__popcll(__ballot((ntop >> b) & 1u))) << b;
                 if (tally_by_ballot) {
                     const uint32_t upm = actm & vld & ~alow;
-#pragma unroll
+#pragma unroll 4
                     for (int it = 0; it < ITS; ++it) tally((upm >> (31 - it)) & 1u, uint32_t(acode >> (62 - 2 * it)) & 3u);
                 } else {
                     const uint32_t lowm = actm & vld & alow;
                     if (__ballot(lowm != 0)) {
-#pragma unroll
+#pragma unroll 1
                         for (int it = 0; it < ITS; ++it) tally((lowm >> (31 - it)) & 1u, uint32_t(acode >> (62 - 2 * it)) & 3u);
                     }
                 }
@@ -242,7 +268,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 }
             }
             __syncthreads();
-            if (tid < FRISK_MISC_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
+            if (tid < FRISK8_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
 
             // ---- stage 2: C_5[q] = D_5[q] + (sum of the 64 order-8 counters below q); grand total for the overflow check
             const uint32_t o5 = uint32_t(table_offset(kmin, 5));
@@ -321,7 +347,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const bool wrapped = uni(misc[M8_TSUM]) != nvalid_top || n_orph > FRISK8_ORPH_CAP;
 
             auto zero_own = [&]() {             // every max-mer position clears its dword (all reads are behind a barrier)
-#pragma unroll
+#pragma unroll 4
                 for (int it = 0; it < ITS; ++it)
                     if (fullm & (0x80000000u >> it)) t8[code_at(it) >> SHW] = 0u;
             };
@@ -331,9 +357,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 if (tid == 0) {
                     if (wrapped) {
                         // a counter wrapped (every sum above is then unreliable, the N filter's included), or too many
-                        // orphans: scan_kernel.h's 16-bit form redoes this window from scratch
-                        const unsigned int slot = atomicAdd(P.ovf_count, 1u);
-                        P.ovf_list[slot] = cand;
+                        // orphans: the next wider form (8-bit, then scan_kernel.h's 16-bit) redoes this window from scratch
+                        const unsigned int slot = atomicAdd(P.out_count, 1u);
+                        P.out_list[slot] = cand;
                     } else {
                         P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop;
                         P.status[row] = status;
@@ -350,43 +376,63 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             if (tid == 0) { P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop; }
 
-            // the orphan list in scalar registers: oe7 = the entry as stored (a run-7 entry equals its 7-mer, a run-6 entry
-            // has bit 15 set and equals none), oe6 = the entry's 6-mer.  A window without invalid bases has exactly two.
-            uint32_t oe7[4], oe6[4];
+            // The orphan list in scalar registers.  A run-7 entry is its 7-mer; a run-6 entry has bit 15 set.  o6[k] = the
+            // 6-mer of entry k (both kinds count towards c6), o7[0..n7) = the 7-mers of the run-7 entries.  A window without
+            // invalid bases has exactly one of each kind (its tail).
+            uint32_t o6[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, o7[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            int n7 = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                oe7[k] = 0xFFFFFFFFu; oe6[k] = 0xFFFFFFFFu;
                 if (k < n_orph) {
                     const uint32_t e = uni(uint32_t(orph[k]));
-                    oe7[k] = e; oe6[k] = (e >> 2) & 0xFFFu;
+                    o6[k] = (e >> 2) & 0xFFFu;
+                    if (!(e & 0x8000u)) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (q == n7) o7[q] = e;
+                        ++n7;
+                    }
                 }
             }
-            // counts of the three top orders for the max-mer `c16`, from ONE aligned read.  ORPH: bound on the orphan list
-            // known to the caller (2, 4, or 0 = any length)
-            auto top_counts = [&](uint32_t c16, auto orph_c, uint32_t& c8, uint32_t& c7, uint32_t& c6) __attribute__((always_inline)) {
+            // what a max-mer position reads, all of it addressed by the code alone (so it can be fetched ahead of use):
+            // genome-side value, the order-8 counters of its 6-mer / 7-mer / itself, the shared-prefix sums
+            struct Fetched { double Ig, A5; uint32_t W5, c8, w7; uint4 w6; };
+            auto fetch = [&](uint32_t c16) __attribute__((always_inline)) -> Fetched {
+                Fetched f;
+                f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^8 always
+                if (BITS == 8) {        // the counter of code c is byte c of the table
+                    f.c8 = t8b[c16];
+                    f.w7 = *reinterpret_cast<const uint32_t*>(t8b + (c16 & 0xFFFCu));
+                    f.w6 = *reinterpret_cast<const uint4*>(t8b + (c16 & 0xFFF0u));
+                } else {                // the four nibbles of the 7-mer c >> 2 are the 16 bits at byte 2 (c >> 2)
+                    f.c8 = 0;
+                    f.w7 = *reinterpret_cast<const uint16_t*>(t8b + ((c16 >> 2) << 1));
+                    const uint2 x = *reinterpret_cast<const uint2*>(t8b + ((c16 >> 4) << 3));
+                    f.w6 = make_uint4(x.x, x.y, 0u, 0u);
+                }
+                const uint32_t pc = c16 >> 6;
+                f.W5 = pre_w[pc];
+                f.A5 = pre_i[pc];
+                return f;
+            };
+            // counts of the three top orders of the max-mer c16.  ORPH: what the caller knows about the orphan list -
+            // 2: at most two entries, at most one of them a 7-mer (the usual window); 4: at most four entries; 0: any length
+            auto top_counts = [&](const Fetched& f, uint32_t c16, auto orph_c, uint32_t& c8, uint32_t& c7, uint32_t& c6) __attribute__((always_inline)) {
                 constexpr int ORPH = decltype(orph_c)::value;
                 const uint32_t q6 = c16 >> 4, q7 = c16 >> 2;
                 if (BITS == 8) {
-                    const uint4 tw = *reinterpret_cast<const uint4*>(t8b + q6 * 16u);
-                    const uint32_t lo = (c16 & 4u) ? tw.y : tw.x, hi = (c16 & 4u) ? tw.w : tw.z;
-                    const uint32_t w = (c16 & 8u) ? hi : lo;
-                    c8 = __builtin_amdgcn_ubfe(w, (c16 & 3u) * 8u, 8u);
-                    c7 = __builtin_amdgcn_sad_u8(w, 0u, 0u);
-                    c6 = __builtin_amdgcn_sad_u8(tw.x, 0u, __builtin_amdgcn_sad_u8(tw.y, 0u, __builtin_amdgcn_sad_u8(tw.z, 0u, __builtin_amdgcn_sad_u8(tw.w, 0u, 0u))));
+                    c8 = f.c8;
+                    c7 = __builtin_amdgcn_sad_u8(f.w7, 0u, 0u);
+                    c6 = __builtin_amdgcn_sad_u8(f.w6.x, 0u, __builtin_amdgcn_sad_u8(f.w6.y, 0u, __builtin_amdgcn_sad_u8(f.w6.z, 0u, __builtin_amdgcn_sad_u8(f.w6.w, 0u, 0u))));
                 } else {
-                    const uint2 tw = *reinterpret_cast<const uint2*>(t8b + q6 * 8u);
-                    const uint32_t w = (c16 & 8u) ? tw.y : tw.x;
-                    const uint32_t f = __builtin_amdgcn_ubfe(w, (c16 & 4u) * 4u, 16u);
-                    c8 = __builtin_amdgcn_ubfe(f, (c16 & 3u) * 4u, 4u);
-                    c7 = __builtin_amdgcn_udot8(f, 0x1111u, 0u, false);
-                    c6 = __builtin_amdgcn_udot8(tw.x, 0x11111111u, __builtin_amdgcn_udot8(tw.y, 0x11111111u, 0u, false), false);
+                    c8 = __builtin_amdgcn_ubfe(f.w7, (c16 & 3u) * 4u, 4u);
+                    c7 = __builtin_amdgcn_udot8(f.w7, 0x1111u, 0u, false);
+                    c6 = __builtin_amdgcn_udot8(f.w6.x, 0x11111111u, __builtin_amdgcn_udot8(f.w6.y, 0x11111111u, 0u, false), false);
                 }
-                constexpr int NS = ORPH == 2 ? 2 : 4;
+                constexpr int N6 = ORPH == 2 ? 2 : 4, N7 = ORPH == 2 ? 1 : 4;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    c7 += (q7 == oe7[k]) ? 1u : 0u;
-                    c6 += (q6 == oe6[k]) ? 1u : 0u;
-                }
+                for (int k = 0; k < N7; ++k) c7 += (q7 == o7[k]) ? 1u : 0u;
+#pragma unroll
+                for (int k = 0; k < N6; ++k) c6 += (q6 == o6[k]) ? 1u : 0u;
                 if (ORPH == 0)
                     for (int k = 4; k < n_orph; ++k) {
                         const uint32_t e = orph[k];
@@ -401,7 +447,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             auto count = [&](int x, uint32_t c) -> uint32_t {
                 if (x <= 5) return small16[table_offset(kmin, x) + c];
                 uint32_t c8, c7, c6;
-                top_counts(c << (2 * (8 - x)), orphN{}, c8, c7, c6);
+                const uint32_t c16 = c << (2 * (8 - x));
+                top_counts(fetch(c16), c16, orphN{}, c8, c7, c6);
                 return x == 8 ? c8 : (x == 7 ? c7 : c6);
             };
 
@@ -423,9 +470,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     ox[x] = on ? uint32_t(table_offset(kmin, x)) : 0u;
                     wm[x] = on ? 0xFFFFFFFFu : 0u;
                 }
-#pragma unroll
-                for (int e = 0; e < 1024 / NT; ++e) {
-                    const uint32_t c = tid + e * NT;
+#pragma unroll 2
+                for (uint32_t c = tid; c < 1024u; c += NT) {
                     uint32_t cx[LV + 1];
 #pragma unroll
                     for (int x = 1; x <= LV; ++x) cx[x] = small16[ox[x] + (c >> (2 * (LV - x)))];
@@ -478,37 +524,60 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // a position that starts no max-mer must add exactly nothing: clearing the HIGH word of its term leaves a
             // subnormal or zero, whatever garbage (NaN included) its lanes computed
             auto only_on = [](bool on, double x) -> double { return __hiloint2double(on ? __double2hiint(x) : 0, __double2loint(x)); };
-            auto score_one = [&](uint32_t c16, bool on, auto orph_c) __attribute__((always_inline)) {
-                const double Ig = P.ig[c16];                                 // unconditional gather (c16 < 4^8 always)
+            auto score_one = [&](const Fetched& f, uint32_t c16, bool on, auto orph_c) __attribute__((always_inline)) {
                 uint32_t c8, c7, c6;
-                top_counts(c16, orph_c, c8, c7, c6);
-                const uint32_t pc = c16 >> 6;
-                const uint32_t W = pre_w[pc] + (c6 << 12) + (c7 << 14) + (c8 << 16);
-                double A = pre_i[pc];
-                const double d6 = double(c6), d7 = double(c7), d8 = double(c8);
-                A = __builtin_fma(d6 * d6, r6, A);
-                A = __builtin_fma(d7 * d7, r7, A);
-                A = __builtin_fma(d8 * d8, r8, A);
+                top_counts(f, c16, orph_c, c8, c7, c6);
+                double rc = rctab[c8 & 15u];                                 // 1/c8 (1.0 for the 19 in 20 max-mers seen once)
+                if (BITS == 8 && __builtin_expect(__any(c8 >= 16u), 0)) {     // (wave-uniform, rare: low-complexity sequence)
+                    if (c8 >= 16u) {                                          // beyond the table: reciprocal + two Newton steps
+                        const double dc = double(c8);
+                        double r = __builtin_amdgcn_rcp(dc);
+                        r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                        r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                        rc = r;
+                    }
+                }
+                const uint32_t W = f.W5 + (c6 << 12) + (c7 << 14) + (c8 << 16);
+                // c^2 exactly, as integers (< 2^32), then 4^x / D_x times it
+                double A = __builtin_fma(double(__umul24(c6, c6)), r6, f.A5);
+                A = __builtin_fma(double(__umul24(c7, c7)), r7, A);
+                A = __builtin_fma(double(__umul24(c8, c8)), r8, A);
                 // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
-                const double ratio = div_exact(A, double(W) * Ig);
-                const double Iw = ratio * Ig;
-                const double t = Iw * log_tab_pos(ratio, logtab);
-                const double rc = rctab[c8];                                 // 1/c8 (exactly 1.0 for the 9 in 10 max-mers seen once)
-                sw += only_on(on, Iw * rc);
-                sg += only_on(on, Ig * rc);
-                stt += only_on(on, t * rc);
+                const double ratio = div_exact(A, double(W) * f.Ig);
+                const double Iwr = (ratio * f.Ig) * rc;                      // this position's share of Iw
+                const double ln = log_tab_n<LOGN, LOGDEG>(ratio, logtab);
+                sw += only_on(on, Iwr);
+                sg += only_on(on, f.Ig * rc);
+                stt += only_on(on, Iwr * ln);
             };
-            auto score_all = [&](auto orph_c) __attribute__((always_inline)) {
-#pragma unroll
-                for (int it = 0; it < ITS; ++it) {
-                    score_one(code_at(it), (fullm >> (31 - it)) & 1u, orph_c);
+            // the lane's codes and flags again, opaque to the optimiser: without this it keeps every position's pre-shifted
+            // code variants of stage 1 alive across the whole window (60 registers) instead of re-deriving them here
+            uint32_t ah = uint32_t(acode >> 32), al = uint32_t(acode), fm4 = fullm;
+            asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
+            const uint64_t acode4 = (uint64_t(ah) << 32) | al;
+            auto code4_at = [&](int it) -> uint32_t { return uint32_t(acode4 >> (48 - 2 * it)) & 0xFFFFu; };
 #ifndef FRISK8_S4_GROUP
 #define FRISK8_S4_GROUP 2
 #endif
-                    if ((it % FRISK8_S4_GROUP) == FRISK8_S4_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+            auto score_all = [&](auto orph_c) __attribute__((always_inline)) {
+                constexpr int GR = FRISK8_S4_GROUP;
+                // software pipeline, fully unrolled: the reads of group g+1 are issued before the arithmetic of group g.
+                // (A rolled loop - two groups per trip, ping-pong buffers - needs 86..129 registers and no scratch, but
+                // measured 4..6 % slower at three workgroups per CU; thread counts 320 / 384 / 512 per workgroup 18..60 %.)
+                Fetched buf[2][GR];
+#pragma unroll
+                for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k));
+#pragma unroll
+                for (int g = 0; g < ITS; g += GR) {
+                    const int cur = (g / GR) & 1;
+#pragma unroll
+                    for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k));
+#pragma unroll
+                    for (int k = 0; k < GR; ++k) if (g + k < ITS) score_one(buf[cur][k], code4_at(g + k), (fm4 >> (31 - (g + k))) & 1u, orph_c);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (n_orph <= 2) score_all(orph2{});
+            if (n_orph <= 2 && n7 <= 1) score_all(orph2{});
             else if (n_orph <= 4) score_all(orph4{});
             else score_all(orphN{});
 
@@ -516,7 +585,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             sw = wave_sum_exact(sw); sg = wave_sum_exact(sg); stt = wave_sum_exact(stt);
             if (lane == 0) { double* p = scratch + (tid >> 6) * 3; p[0] = sw; p[1] = sg; p[2] = stt; }
             __syncthreads();
-            zero_own();                                     // behind the barrier: nobody reads the tables any more
+#pragma unroll 4
+            for (int it = 0; it < ITS; ++it)                // behind the barrier: nobody reads the tables any more
+                if (fm4 & (0x80000000u >> it)) t8[code4_at(it) >> SHW] = 0u;
             clear_small();
             if (tid == 0) {
                 double a = 0.0, b = 0.0, c = 0.0;

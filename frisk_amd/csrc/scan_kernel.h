@@ -48,6 +48,8 @@ struct ScanParams {
     const ScafDesc* descs;
     const double* ig;         // genome-side IVOM, 4^kmax entries (NaN = zero weight)
     const double* log_tab;    // FRISK_LOGTAB_N pairs {1/c_i, ln c_i}: range reduction of log_tab_pos()
+    const double* log_tab64;  // the same with 64 bins (scan8_kernel.h, where LDS is short)
+    const double* log_tab32;  // ... and with 32
     int32_t n_desc;
     int32_t kmin, kmax;
     int32_t w, inc;
@@ -73,11 +75,14 @@ struct ScanParams {
     uint32_t* dbg_counts;
     int64_t* dbg_meta;
     unsigned long long* stamps;   // -DFRISK_STAMPS builds only: s_memtime at the stage boundaries of the first workgroups
-    // hand-over from scan8_kernel.h (narrow order-8 counters) to this file's 16-bit form: windows whose counters wrapped
+    // scan8_kernel.h (narrow order-8 counters): windows whose counters wrap are handed to the next wider form through
+    // device-side lists of candidate indices
     const double* rc_tab;         // 1/c for c = 0..255 (entry 0 = 0): the weight of one of the c positions that share a max-mer
-    int64_t* ovf_list;            // candidate indices appended by scan8_kernel ...
-    unsigned int* ovf_count;      // ... and their number
-    int32_t from_list;            // != 0: scan_kernel takes its candidates from ovf_list[0 .. *ovf_count) instead of [c0, c1)
+    const int64_t* in_list;       // != nullptr: take the candidates from in_list[0 .. *in_count) instead of [c0, c1)
+    const unsigned int* in_count;
+    int64_t* out_list;            // scan8_kernel appends the windows it could not hold ...
+    unsigned int* out_count;      // ... and counts them
+    int32_t sel_mode, sel_mod;    // scan8_kernel, range mode: 0 all chunks, 1 every sel_mod-th chunk, 2 all the others
 };
 
 #define ROW_KEPT 1u
@@ -425,9 +430,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     const int G = gridDim.x;
     int v = blockIdx.x;
     if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    // candidates: the range [c0, c1) in chunks, or (from_list) the windows that scan8_kernel handed over, one at a time
-    const bool listed = P.from_list != 0;
-    const int64_t ncand = listed ? int64_t(*P.ovf_count) : P.c1 - P.c0;
+    // candidates: the range [c0, c1) in chunks, or (in_list) the windows that scan8_kernel handed over, one at a time
+    const bool listed = P.in_list != nullptr;
+    const int64_t ncand = listed ? int64_t(*P.in_count) : P.c1 - P.c0;
     const int64_t chunk = listed ? 1 : P.chunk;
     const int64_t nchunks = (ncand + chunk - 1) / chunk;
 
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
         const int64_t cb = listed ? q : P.c0 + q * chunk;
         const int64_t ce = listed ? q + 1 : ((cb + chunk < P.c1) ? cb + chunk : P.c1);
         for (int64_t ci = cb; ci < ce; ++ci) {
-            const int64_t cand = listed ? P.ovf_list[ci] : ci;
+            const int64_t cand = listed ? P.in_list[ci] : ci;
             // ---- which scaffold / window is this candidate? (uniform across the workgroup)
             if (cand < d.cand0 || cand >= d.cand0 + d.ncand) {
                 int lo = 0, hi = P.n_desc - 1;

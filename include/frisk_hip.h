@@ -125,10 +125,11 @@ int frisk_scan(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int64_t c
                double* kld, double* gc, double* pi, double* si, double* cri,
                uint32_t* dbg_counts, int64_t* dbg_meta);
 
-/* Diagnostic: how many windows of the most recent frisk_scan were redone with 16-bit counters because one of their
- * 8-mers occurred more often than the narrow counters of the default K = 8 kernel hold (low-complexity sequence).
- * Results do not depend on it. */
-int64_t frisk_last_scan_overflow(const frisk_ctx* ctx);
+/* Diagnostics of the most recent frisk_scan (results never depend on them).  The default K = 8 kernel counts max-mers in
+ * 4- or 8-bit counters and hands a window with a more frequent max-mer (low-complexity sequence) to the next wider form:
+ * which = 0: counter width of the bulk launch (4 or 8; 16 = the narrow kernel was not used),
+ *         1: windows handed from 4-bit to 8-bit counters,   2: windows handed on to 16-bit counters. */
+int64_t frisk_last_scan_stat(const frisk_ctx* ctx, int which);
 
 /* Page-locked host memory for result buffers: D2H copies into it are asynchronous and run at PCIe rate
  * (pageable buffers work too, at a fraction of it).  Free with frisk_host_free before frisk_destroy. */

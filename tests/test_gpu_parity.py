@@ -475,3 +475,50 @@ def test_windows_beyond_lds_counters_against_c_oracle(kmin, kmax, w, inc, scaffo
             assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
     assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
     assert np.array_equal(res.kld, res2.kld, equal_nan=True) and np.array_equal(res.status, res2.status)
+
+
+@pytest.mark.parametrize("every,expect_bulk", [(60000, 4), (9000, 8)])
+def test_adaptive_counter_width_and_handover(every, expect_bulk):
+    """The default K = 8 kernel counts max-mers in 4- or 8-bit counters (scan8_kernel.h) and hands windows with a more
+    frequent max-mer to the next wider form: 4-bit -> 8-bit -> 16-bit.  A 12 Mb genome with microsatellites and poly-A
+    runs (a few of them longer than 8-bit counters hold) sprinkled in: every row must still equal the compiled oracle's,
+    the hand-over lists must have been used, and the sample must have picked the expected width for the bulk."""
+    from oracle import frisk_oracle_c as OC
+    from frisk_amd import _ffi, synth
+    n = 12_000_000
+    s = np.frombuffer(synth.scaffold(n, 77, 0, island_frac=0.05, n_frac=0.01, lower_frac=0.01), dtype=np.uint8).copy()
+    rng = np.random.default_rng(every)
+    units = [b"A", b"T", b"CA", b"TG", b"AAT", b"GATA", b"TTAGGG"]
+    for a in range(5000, n - 3000, every):
+        a += int(rng.integers(0, every // 3))
+        u = units[int(rng.integers(0, len(units)))]
+        ln = int(rng.choice([24, 40, 60, 90, 300, 700]))                       # 300+: wraps 8-bit counters as well
+        rep = (u * (ln // len(u) + 1))[:ln]
+        s[a:a + ln] = np.frombuffer(rep, dtype=np.uint8)
+    seqs = [s.tobytes()]
+    with make_engine(1, 8) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        res = e.scan(5000, 1000, rip=True)
+        stat = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
+        sub = e.scan(5000, 1000, rip=True, c0=1234, c1=4321)                   # another range: another sample, other widths
+        few = e.scan(5000, 1000, rip=True, c0=700, c1=1000)                     # too few windows to sample: 8-bit bulk
+        stat_few = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
+    assert stat[0] == expect_bulk, stat
+    assert stat[1] > 50 and stat[2] > 5, stat                                  # both hand-over lists were used
+    assert stat_few[0] == 8 and stat_few[1] == 0, stat_few
+    for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):        # same bits whichever form scored the window
+        assert np.array_equal(getattr(sub, f), getattr(res, f)[1234:4321], equal_nan=True), f
+        assert np.array_equal(getattr(few, f), getattr(res, f)[700:1000], equal_nan=True), f
+    S = OC.Seqs(seqs)
+    osym, ometa = OC.genome_profile(S, 1, 8)
+    assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+    exp = OC.scan(S, OC.genome_ivom(osym, ometa, 1, 8), 1, 8, 5000, 1000, rip=True)
+    k = np.nonzero(res.kept)[0]
+    assert len(k) == len(exp["kld"])
+    assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"])
+    assert np.array_equal(res.gc[k], exp["gc"])
+    for col in ("pi", "si", "cri"):
+        assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
+    assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11

@@ -13,7 +13,7 @@ from frisk_amd import Engine, synth  # noqa: E402
 from frisk_amd import _ffi  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "8", "4"]
+variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["16", "8", "4", "0"]
 CONFIGS = [
     ("C5/8 shard w=5000 i=1000", [max(1, int(x * scale)) for x in synth.c5_shard_lens(8, 0)], 5000, 1000, 0.07),
     ("C4 w=2000 i=500", [int(synth.C4_LENS[0] * scale)], 2000, 500, 0.07),
@@ -32,7 +32,7 @@ for name, lens, w, inc, nfrac in CONFIGS:
                 ts.append(e.kernel_ms(0))
             k = r.kept
             kld = r.kld[k].copy()
-            ovf = int(_ffi.lib().frisk_last_scan_overflow(e._ctx))
+            ovf = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
             if ref is None:
                 ref = kld
             print(json.dumps({"config": name, "bits": bits, "candidates": int(r.n_candidates), "rows": int(k.sum()),
