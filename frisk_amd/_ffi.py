@@ -44,6 +44,7 @@ SYMBOLS = [
     ("frisk_scan_plan", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, _I64P]),
     ("frisk_scan", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("frisk_scan_ivom", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     ("frisk_last_scan_stat", C.c_int64, [_P, C.c_int]),
     ("frisk_host_alloc", C.c_void_p, [_P, C.c_int64]),
     ("frisk_host_free", None, [_P, _P]),

@@ -83,7 +83,8 @@ struct frisk_ctx {
     DevBuf<int32_t> o_seq;
     DevBuf<int64_t> o_start, o_stop, o_meta;
     DevBuf<uint32_t> o_status, o_counts;
-    DevBuf<double> o_kld, o_gc, o_pi, o_si, o_cri, o_sw, o_sg;
+    DevBuf<double> o_kld, o_gc, o_pi, o_si, o_cri, o_sw, o_sg, o_ivom;
+    double* want_ivom = nullptr;     // frisk_scan_ivom: host buffer of the per-max-mer dump requested from the next debug scan
 };
 
 namespace {
@@ -297,7 +298,7 @@ void frisk_destroy(frisk_ctx* c) {
     c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_logtab64.release(); c->d_logtab32.release(); c->d_rctab.release(); c->d_ovf_list.release(); c->d_ovf_list2.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
-    c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
+    c->o_ivom.release(); c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -687,6 +688,13 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.pi = rip ? c->o_pi.p : nullptr; P.si = rip ? c->o_si.p : nullptr; P.cri = rip ? c->o_cri.p : nullptr;
     P.dbg_counts = dbg_counts ? c->o_counts.p : nullptr;
     P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
+    P.dbg_ivom = nullptr;
+    const size_t nk = size_t(1) << (2 * c->kmax);
+    if (c->want_ivom) {
+        HIPC(c, c->o_ivom.reserve(N * 2 * nk));
+        HIPC(c, hipMemsetAsync(c->o_ivom.p, 0, N * 2 * nk * sizeof(double), c->stream));
+        P.dbg_ivom = c->o_ivom.p;
+    }
     P.stamps = nullptr;
     P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
     P.sel_mode = 0; P.sel_mod = 16;
@@ -864,6 +872,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     if (dbg_counts)
         HIPC(c, hipMemcpyAsync(dbg_counts, c->o_counts.p, N * size_t(c->nprof) * 4, hipMemcpyDeviceToHost, c->stream));
     if (dbg_meta) HIPC(c, hipMemcpyAsync(dbg_meta, c->o_meta.p, N * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->want_ivom) HIPC(c, hipMemcpyAsync(c->want_ivom, c->o_ivom.p, N * 2 * nk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     unsigned int novf[2] = {0, 0};
     if (narrow) HIPC(c, hipMemcpyAsync(novf, c->d_ovf_count.p, sizeof(novf), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -872,6 +881,41 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     float ms = 0;
     HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->ms[0] = ms;
+    return FRISK_OK;
+}
+
+int frisk_scan_ivom(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1, int64_t cap,
+                    double* window_ivom, double* genome_ivom) {
+    if (!c || !window_ivom || !genome_ivom) return FRISK_E_ARG;
+    if (c->kmax > 6) return fail(c, FRISK_E_ARG, "frisk_scan_ivom: the per-max-mer dump exists for kmax <= 6 only");
+    int64_t ncand = 0;
+    int rc = frisk_scan_plan(c, w, inc, flags, &ncand);
+    if (rc) return rc;
+    if (c1 < 0) c1 = ncand;
+    if (c0 < 0 || c0 > c1 || c1 > ncand) return fail(c, FRISK_E_ARG, "candidate range outside [0, n_candidates]");
+    const int64_t n = c1 - c0;
+    if (cap < n) return fail(c, FRISK_E_CAP, "output capacity too small: need " + std::to_string(n));
+    if (c->plan_maxwin > 65535) return fail(c, FRISK_E_ARG, "frisk_scan_ivom: windows of at most 65535 bases");
+    const size_t nk = size_t(1) << (2 * c->kmax), N = size_t(std::max<int64_t>(n, 1));
+    std::vector<double> raw(N * 2 * nk), kld(N), gc(N), pi(N), si(N), cri(N);
+    std::vector<int32_t> seq(N);
+    std::vector<int64_t> start(N), stop(N), meta(N * 3);
+    std::vector<uint32_t> status(N);
+    c->want_ivom = raw.data();
+    rc = frisk_scan(c, w, inc, flags & ~FRISK_SCAN_RIP, c0, c1, int64_t(N), seq.data(), start.data(), stop.data(), status.data(),
+                    kld.data(), gc.data(), nullptr, nullptr, nullptr, nullptr, meta.data());
+    c->want_ivom = nullptr;
+    if (rc) return rc;
+    for (int64_t r = 0; r < n; ++r) {           // normalise over the window's present max-mers (L450-454), in index order
+        const double* iw = raw.data() + size_t(r) * 2 * nk;
+        const double* ig = iw + nk;
+        double sw = 0.0, sg = 0.0;
+        for (size_t k = 0; k < nk; ++k) { sw += iw[k]; sg += ig[k]; }
+        for (size_t k = 0; k < nk; ++k) {
+            window_ivom[size_t(r) * nk + k] = iw[k] != 0.0 ? iw[k] / sw : 0.0;
+            genome_ivom[size_t(r) * nk + k] = iw[k] != 0.0 ? ig[k] / sg : 0.0;
+        }
+    }
     return FRISK_OK;
 }
 

@@ -74,6 +74,7 @@ struct ScanParams {
     double* cri;
     uint32_t* dbg_counts;
     int64_t* dbg_meta;
+    double* dbg_ivom;             // debug, kmax <= 6: row x 2 x 4^kmax - un-normalised window-side and genome-side IVOM per max-mer
     unsigned long long* stamps;   // -DFRISK_STAMPS builds only: s_memtime at the stage boundaries of the first workgroups
     // scan8_kernel.h (narrow order-8 counters): windows whose counters wrap are handed to the next wider form through
     // device-side lists of candidate indices
@@ -1000,6 +1001,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                 else Wd = window_ivom(Tm, code, plain_c, lv_c, A);
                 const double ratio = (FRISK_ABL & 2) ? A * (Wd * Ig) : div_exact(A, Wd * Ig);
                 const double Iw = ratio * Ig;
+                if (DEBUG && P.dbg_ivom && rep) {       // IvomBuild's per-max-mer values before normalisation (L442-450)
+                    double* o = P.dbg_ivom + (row * 2) * (int64_t(1) << (2 * kmax));
+                    o[code] = Iw;
+                    o[(int64_t(1) << (2 * kmax)) + code] = Ig;
+                }
                 // Iw ln(Iw/Ig): the log of the RATIO (|ln| ~ 1) keeps the absolute error of T at the 1e-16 level
 #ifdef FRISK_LOG_FDLIBM
                 const double t = Iw * log_pos(ratio);

@@ -232,5 +232,22 @@ class Engine:
         r.n_candidates = total
         return r
 
+    def scan_ivom(self, w, inc, scaffolds_all=False, c0=0, c1=-1):
+        """(window_ivom, genome_ivom): IvomBuild's two normalised distributions per candidate window as dense
+        [n, 4^kmax] arrays (test utility, kmax <= 6)."""
+        flags = _ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0
+        total = self.scan_plan(w, inc, scaffolds_all)
+        if c1 < 0:
+            c1 = total
+        n = max(c1 - c0, 0)
+        wi = np.zeros((max(n, 1), 4 ** self.kmax), np.float64)
+        gi = np.zeros_like(wi)
+        self._check(self._lib.frisk_scan_ivom(self._ctx, int(w), int(inc), flags, int(c0), int(c1), max(n, 1), _ptr(wi), _ptr(gi)))
+        return wi[:n], gi[:n]
+
+    def scan_stat(self):
+        """(counter width of the bulk launch, windows handed 4->8 bit, windows handed on to 16 bit) of the last scan."""
+        return tuple(int(self._lib.frisk_last_scan_stat(self._ctx, i)) for i in range(3))
+
     def kernel_ms(self, which=0):
         return float(self._lib.frisk_last_kernel_ms(self._ctx, which))

@@ -91,8 +91,9 @@ class HotPath:
         rip = bool(getattr(args, "RIP", False)) and args.minWordSize <= 2
         if rip and args.maxWordSize < 2:
             raise ValueError("2 is not in list")        # range(m, K+1).index(2), reference L478
+        # (ordinary numpy arrays: `res` is handed to the caller and must outlive the next scan and Engine.close())
         res = self.engine.scan(args.windowlen, args.increment, rip=rip,
-                               scaffolds_all=bool(getattr(args, "scaffoldsAll", False)), debug=debug, pinned=not debug)
+                               scaffolds_all=bool(getattr(args, "scaffoldsAll", False)), debug=debug, pinned=False)
         kept = np.nonzero(res.kept)[0]
         bad = kept[(res.status[kept] & _ffi.ROW_ZERO_WEIGHT) != 0]
         rows = []

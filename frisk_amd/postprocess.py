@@ -10,6 +10,7 @@ book-ended features merge at D = 0; numeric summaries printed with bedtools' def
 Parity for that part is pinned by construction and by tests only, not by the reference's own output.
 """
 import math
+import os
 import re
 
 import numpy as np
@@ -146,7 +147,8 @@ def thresholdKLD(table, threshold, args, merge=True):
     if merge:
         feats = merge_intervals(recs, dist=getattr(args, "mergeDist", 0), ops=("max", "min", "mean"), cols=(3, 3, 3))
     else:
-        feats = [(c, s, e, str(v)) for c, s, e, v in recs]
+        fmt = py3_str if os.environ.get("FRISK_FLOAT_REPR", "py2") == "py3" else py2_str    # the table's float text
+        feats = [(c, s, e, fmt(v)) for c, s, e, v in recs]
     return feats, chosen
 
 

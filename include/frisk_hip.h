@@ -125,6 +125,12 @@ int frisk_scan(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int64_t c
                double* kld, double* gc, double* pi, double* si, double* cri,
                uint32_t* dbg_counts, int64_t* dbg_meta);
 
+/* Test utility (kmax <= 6): the two distributions IvomBuild returns for each candidate window of [c0,c1) (L1481-1482, L369-457) -
+ * window-side and genome-side interpolated probabilities of the window's present max-mers, each normalised to sum 1 -
+ * as dense vectors of 4^kmax doubles per candidate (0 for absent max-mers; all 0 for windows the reference drops). */
+int frisk_scan_ivom(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1, int64_t cap,
+                    double* window_ivom, double* genome_ivom);
+
 /* Diagnostics of the most recent frisk_scan (results never depend on them).  The default K = 8 kernel counts max-mers in
  * 4- or 8-bit counters and hands a window with a more frequent max-mer (low-complexity sequence) to the next wider form:
  * which = 0: counter width of the bulk launch (4 or 8; 16 = the narrow kernel was not used),

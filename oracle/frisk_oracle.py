@@ -96,6 +96,14 @@ def kmer_of(code, x):
     return "".join(BASES[(code >> (2 * (x - 1 - p))) & 3] for p in range(x))
 
 
+def code_of(kmer):
+    """Canonical index of a k-mer: digits A=0,T=1,G=2,C=3, first base most significant (L70, L253-274)."""
+    c = 0
+    for ch in kmer:
+        c = c * 4 + BASES.index(ch)
+    return c
+
+
 def blank_maps(kmin, kmax):
     """One dict per order, every k-mer -> 0, keys in canonical index order (L253-274)."""
     return [{kmer_of(c, x): 0 for c in range(4 ** x)} for x in range(kmin, kmax + 1)]
@@ -219,6 +227,7 @@ def score_window(seq, genome_maps, genome_meta, kmin, kmax, rip=False):
         g = ivom(wmaps, wmeta, genome_maps, genome_meta, kmin, kmax)
         w = ivom(wmaps, wmeta, wmaps, wmeta, kmin, kmax)
         row["KLD"] = kld(g, w)
+        row["ivom"] = (g, w)            # IvomBuild's two return values (L1481-1482), for the golden IVOM vectors
     except ZeroDivisionError:
         row["error"] = "ZeroDivisionError"
     try:

@@ -31,6 +31,9 @@ class Case:
         self.genome_meta = self.doc["genome_meta"]
         self.genome_counts = self.arrays["genome_counts"]
         self.window_counts = self.arrays["window_counts"]
+        # IvomBuild's normalised distributions per row, dense over 4^k max-mers (stored for the small-K cases only)
+        self.window_ivom = self.arrays["window_ivom"] if "window_ivom" in self.arrays.files else None
+        self.genome_ivom = self.arrays["genome_ivom"] if "genome_ivom" in self.arrays.files else None
 
     @property
     def rip_on(self):

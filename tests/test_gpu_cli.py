@@ -76,3 +76,33 @@ def test_cli_sharded_path_in_one_rank_group(tmp_path, capsys, monkeypatch):
             dist.destroy_process_group()
     assert open(tmp_path / "B" / "raw_window_scores.bed").read() == plain
     assert len(plain.splitlines()) == 1 + len(c.rows)
+
+
+def test_cli_hmm_segmentation_gff(tmp_path):
+    """--hmmKLD --hmmOutfile end to end on the GPU (reference L1537-1548, hmm2BED L757-785, hmmBED2GFF L589-596): the
+    GFF3 text the CLI writes equals the text that the host-side model produces from the score table the same run wrote
+    (the model's numbers are parity-unpinned - hmmlearn is absent - but stacking, per-scaffold decoding, run extraction,
+    ordering and the GFF3 layout are the reference's)."""
+    from frisk_amd import postprocess as pp
+    from frisk_amd.cli import main
+    from frisk_amd.hmm import hmm2BED, hmmBED2GFF
+    c = Case("markov_k6")
+    out = tmp_path / "H"
+    assert main(["-H", c.host, "-k", "6", "-w", "400", "-i", "150", "-t", str(out), "-F", "0.08", "--hmmKLD",
+                 "--hmmOutfile", "states.gff3", "--gffOutfile", "anom.gff3"]) == 0
+    table = [ln.split("\t") for ln in open(out / "raw_window_scores.bed").read().splitlines()[1:]]
+    assert len(table) == len(c.rows)
+    rows = [(f[0], int(f[1]), int(f[2]), exp["KLD"], exp["GC"]) for f, exp in zip(table, c.rows)]
+    gff = open(out / "states.gff3").read()
+    lines = gff.splitlines()
+    assert lines[0] == "##gff-version 3"
+    feats = [ln.split("\t") for ln in lines[1:]]
+    assert len(feats) >= 2 and all(len(f) == 9 for f in feats)
+    assert all(f[1] == "frisk_" + pp.FRISK_VERSION for f in feats)
+    assert {f[0] for f in feats} <= {r[0] for r in rows}
+    assert all(1 <= int(f[3]) <= int(f[4]) for f in feats)
+    # the same model on the reference's golden KLD values for these windows gives the same features: the GPU's scores
+    # (within 1e-11 of the reference's) do not move any window across a state boundary
+    intervals, _ = hmm2BED(rows)
+    assert "".join(hmmBED2GFF(intervals)) == gff
+    assert open(out / "anom.gff3").read().startswith("##gff-version 3")

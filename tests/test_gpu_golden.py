@@ -58,3 +58,32 @@ def test_gpu_matches_reference_golden(name):
             assert all(same_float(a, b) for a, b in zip(got, exp["RIP"]))
     assert worst <= KLD_TOL, "max |KLD - reference| = %g" % worst
     print("%s: %d rows, max |dKLD| = %.3g" % (name, len(kept), worst))
+
+
+@pytest.mark.parametrize("name", [n for n in case_names() if Case(n).window_ivom is not None])
+def test_gpu_ivom_vectors_match_reference_golden(name):
+    """IvomBuild (L369-457) itself, not only the scalar KLD it feeds: the GPU's per-max-mer window-side and genome-side
+    interpolated probabilities (frisk_scan_ivom, debug ABI) against the vectors the reference's own IvomBuild returned."""
+    from frisk_amd.hotpath import HotPath
+    c = Case(name)
+    args = SimpleNamespace(hostSeq=c.host, minWordSize=c.m, maxWordSize=c.k, windowlen=c.w, increment=c.i,
+                           maskHost=c.mask_host, scaffoldsAll=c.scaffolds_all, RIP=False, tolerateZeroWeight=True)
+    hp = HotPath(c.m, c.k)
+    try:
+        hp.genomeProfile(args)
+        rows, res = hp.scanGenome(args, c.query or c.host, debug=True)
+        wi, gi = hp.engine.scan_ivom(c.w, c.i, scaffolds_all=c.scaffolds_all)
+    finally:
+        hp.close()
+    kept = np.nonzero(res.kept)[0]
+    assert len(kept) == len(c.rows) == len(c.window_ivom)
+    checked = 0
+    for t, (r, exp) in enumerate(zip(kept.tolist(), c.rows)):
+        if "error" in exp:
+            continue
+        for got, want in ((wi[r], c.window_ivom[t]), (gi[r], c.genome_ivom[t])):
+            assert np.array_equal(got != 0, want != 0)                       # the same set of present max-mers
+            assert np.max(np.abs(got - want) / np.maximum(want, 1e-300)) <= 1e-12
+            assert abs(got.sum() - 1.0) <= 1e-12
+        checked += 1
+    assert checked >= 5

@@ -228,11 +228,13 @@ def test_error_paths_and_edge_batches():
         assert np.all(res.kld[res.kept] > -1e-12)
 
 
-@pytest.mark.parametrize("shape", ["C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("shape", ["C1", "C2", "C3", "C4", "C5"])
 def test_full_size_properties(shape):
     """BASELINE configs at full size: properties that need no oracle run."""
     from frisk_amd import synth
-    if shape == "C2":
+    if shape == "C1":                   # BASELINE configs[0]: single 50 kb scaffold, k=1..4, w=5000 i=1000
+        lens, kmin, kmax, w, inc, nfrac = [50000], 1, 4, 5000, 1000, 0.0
+    elif shape == "C2":
         lens, kmin, kmax, w, inc, nfrac = synth.C2_LENS, 1, 6, 5000, 500, 0.0
     elif shape == "C3":
         lens, kmin, kmax, w, inc, nfrac = synth.C3_LENS, 1, 8, 5000, 1000, 0.001
@@ -242,7 +244,7 @@ def test_full_size_properties(shape):
         lens = [n for r in range(8) for n in synth.c5_shard_lens(8, r)]
         kmin, kmax, w, inc, nfrac = 1, 8, 5000, 1000, 0.07
     with make_engine(kmin, kmax) as e:
-        e.synth(lens, seed={"C2": 2, "C3": 3, "C4": 4, "C5": 5}[shape], island_frac=0.02, n_frac=nfrac)
+        e.synth(lens, seed={"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5}[shape], island_frac=0.02, n_frac=nfrac)
         e.profile_reset(); e.profile_add(); e.profile_finalize()
         sym, tl, ex, nn = e.profile_get()
         assert tl == sum(lens)
@@ -268,8 +270,9 @@ def test_full_size_properties(shape):
                 assert np.all((vals == vals[0]) | (np.isnan(vals) & np.isnan(vals[0])))
             reg = np.nonzero(m & ~jb)[0]
             assert np.array_equal(res.start[reg], 1 + inc * np.arange(len(reg)))
-        # islands exist: the score distribution has a tail
-        assert res.kld[k].max() > 1.3 * np.median(res.kld[k])
+        # islands exist: the score distribution has a tail (C1 is a single 50 kb scaffold: too short to hold one)
+        if shape != "C1":
+            assert res.kld[k].max() > 1.3 * np.median(res.kld[k])
 
 
 def test_rccl_allreduce_path_single_rank():
@@ -354,14 +357,16 @@ def test_many_small_scaffolds():
             assert worst <= KLD_TOL
 
 
-@pytest.mark.parametrize("shape", ["C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("shape", ["C1", "C2", "C3", "C4", "C5"])
 def test_full_size_rows_against_c_oracle(shape):
     """BASELINE configs at full size, row by row against the compiled CPU oracle (oracle/frisk_oracle_c.c, pinned to the
     reference's golden vectors by tests/test_oracle_c.py): profile bit-exact, kept set / coordinates / GC bit-exact,
     KLD to 1e-11.  C2..C4: every window.  C5 (3.3 Gb on one GPU): the full profile and three 20 000-candidate slices."""
     from oracle import frisk_oracle_c as OC
     from frisk_amd import _ffi, synth
-    if shape == "C2":
+    if shape == "C1":
+        lens, kmin, kmax, w, inc, nfrac, slices = [50000], 1, 4, 5000, 1000, 0.0, [(0, -1)]
+    elif shape == "C2":
         lens, kmin, kmax, w, inc, nfrac, slices = synth.C2_LENS, 1, 6, 5000, 500, 0.0, [(0, -1)]
     elif shape == "C3":
         lens, kmin, kmax, w, inc, nfrac, slices = synth.C3_LENS, 1, 8, 5000, 1000, 0.001, [(0, -1)]
@@ -372,11 +377,22 @@ def test_full_size_rows_against_c_oracle(shape):
         kmin, kmax, w, inc, nfrac = 1, 8, 5000, 1000, 0.07
         slices = [(0, 20000), (1_600_000, 1_620_000), (3_260_000, 3_280_000)]
     with make_engine(kmin, kmax) as e:
-        e.synth(lens, seed={"C2": 2, "C3": 3, "C4": 4, "C5": 5}[shape], island_frac=0.02, n_frac=nfrac, lower_frac=0.01)
+        seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5}[shape]
+        kw = dict(island_frac=0.02, n_frac=nfrac, lower_frac=0.01)
+        if shape in ("C1", "C2", "C3"):
+            # the oracle's input is generated on the HOST (frisk_amd/synth.py) and uploaded as ASCII: the GPU's pack, its
+            # counters and its scores are all on the checked path, nothing the oracle sees has passed through the device
+            host = synth_seqs(lens, seed, **kw)
+            e.load(host)
+            S = OC.Seqs(host)
+        else:
+            e.synth(lens, seed=seed, **kw)
+            S = None
         e.profile_reset(); e.profile_add(); e.profile_finalize()
         sym, tl, ex, nn = e.profile_get()
         res = e.scan(w, inc, rip=True)
-        S = OC.Seqs([e.read_seq(q) for q in range(len(lens))])
+        if S is None:                   # 249 Mb / 3.3 Gb: generated on the device, read back (the generators are tested equal)
+            S = OC.Seqs([e.read_seq(q) for q in range(len(lens))])
         osym, ometa = OC.genome_profile(S, kmin, kmax)
         assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
         ig = OC.genome_ivom(osym, ometa, kmin, kmax)
@@ -395,7 +411,7 @@ def test_full_size_rows_against_c_oracle(shape):
             assert np.array_equal((res.status[k] & _ffi.ROW_NO_MAXMER) != 0, (exp["status"] & OC.ROW_NO_MAXMER) != 0)
             assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
             checked += len(k)
-        assert checked > 5000
+        assert checked > (5000 if shape != "C1" else 40)
 
 
 @pytest.mark.parametrize("want_rip", [False, True])

@@ -31,6 +31,16 @@ def test_oracle_matches_reference_golden(name):
         assert got["GC"] == exp["GC"]
         if c.rip_on:
             assert all(same_float(a, b) for a, b in zip(got["RIP"], exp["RIP"]))
+        if c.window_ivom is not None and "error" not in exp:
+            # the per-max-mer interpolated probabilities themselves (IvomBuild L369-457), not only their KLD: bit-exact
+            g, w = got["ivom"]
+            dense_w = np.zeros(4 ** c.k)
+            dense_g = np.zeros(4 ** c.k)
+            for kmer, v in w.items():
+                dense_w[O.code_of(kmer)] = v
+                dense_g[O.code_of(kmer)] = g[kmer]
+            assert np.array_equal(dense_w, c.window_ivom[r])
+            assert np.array_equal(dense_g, c.genome_ivom[r])
 
 
 def test_gzip_fasta_reader(tmp_path):

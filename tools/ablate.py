@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel experiments: build variants of libfrisk_hip.so with -DFRISK_ABLATE=<mask> (or other -D flags) and time
+"""Kernel experiments: build variants of libfrisk_hip.so with -DFRISK_ABL=<mask> (the ingredient mask scan_kernel.h tests; or other -D flags) and time
 the scan / profile kernels of each on one synthetic shard.  Results of ablated builds are WRONG by design; only
 the timings mean anything.  Usage (on the GPU box): python tools/ablate.py 0 1 2 4 8 15"""
 import os
@@ -31,7 +31,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     scale = float(os.environ.get("ABLATE_SCALE", "0.25"))
     for spec in sys.argv[1:]:
-        defs = ["-DFRISK_ABLATE=" + spec] if spec.isdigit() else ["-D" + d for d in spec.split(",")]
+        defs = ["-DFRISK_ABL=" + spec, "-DFRISK_TUNE", "-DFRISK_K8_WIDTH=16"] if spec.isdigit() else ["-D" + d for d in spec.split(",")]
         lib = os.path.join(OUT, "lib_%s.so" % spec.replace(",", "_").replace("=", ""))
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
                         "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", lib,
