@@ -3,7 +3,7 @@
 
 A step = one pass of the hot path over the rank's resident synthetic shard:
     phase A  profile_reset -> profile_add -> [ONE all-reduce of the raw profile over RCCL] -> finalize
-    phase B  window scan of every candidate window (kernel + D2H of the result rows)
+    phase B  window scan of every candidate window (kernels + D2H of the result rows)
 with the packed scaffolds already resident in HBM when the timed region starts.
 
 Workload (config.workload): BASELINE.json's metric geometry k=1..8, w=5000, i=1000 on the C5 shape
@@ -11,8 +11,15 @@ Workload (config.workload): BASELINE.json's metric geometry k=1..8, w=5000, i=10
 shards by longest-processing-time bin packing; every rank owns ONE shard (~388 Mb, ~388 k candidate
 windows), so N = 8 is the full C5 job and N < 8 is the same per-GPU work (weak scaling).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks
+(torch.distributed.run, 127.0.0.1) before anything touches the GPU and relays rank 0's line.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     - HBM roofline of the dominant kernel (scan): algorithmic bytes / HIP-event kernel time
+  roofline     - HBM roofline of the dominant kernel (scan): algorithmic bytes / HIP-event kernel time; `traffic`
+                 and the `binding` block (what actually binds: VALU issue, LDS, waits) come from rocprofv3 PMC passes
+                 of the same workload collected OFFLINE and committed under profiles/ (named in the line)
+  upload       - the same job including host -> HBM: one job from page-locked ASCII, one from the
+                 0.5 B/base packed form, and the steady state with the next batch's upload overlapped (N = 1 only)
   cpu_baseline - the reference-shaped Python oracle timed on one host core on a bounded sample
                  (+ cpu_baseline_numpy, cpu_baseline_c: the vectorised and the compiled multi-thread restatements)
 """
@@ -122,7 +129,66 @@ def cpu_baseline_c(engine, sym, meta, seq0_len, n_windows=60000):
                       "candidate windows of scaffold 0 (%d kept); %.2f s" % (n_windows, len(exp["kld"]), dt)}
 
 
-def main():
+def upload_inclusive(eng, lens, step, fence, steps, rows):
+    """SURVEY.md 8d asks for windows/s over kernel + H2D/D2H.  The genome profile needs EVERY base before the first window
+    can be scored, so inside one job the upload cannot hide behind the scan; it can hide behind the previous job's.
+    Three figures, host buffers page-locked, same shard, same step():
+      single_job_ascii   stage(ASCII, 1 B/base) -> commit -> step          (latency of one job from host memory)
+      single_job_packed  stage(packed, 0.5 B/base) -> commit -> step       (the sequence-cache form)
+      pipelined_ascii    [stage(next) || step(resident)] -> commit, steady state (a stream of batches / jobs)"""
+    import numpy as np
+    total = sum(lens)
+    big = eng.host_array("ascii", total)
+    views, o = [], 0
+    for i, n in enumerate(lens):            # the synthetic shard back to the host once (not timed)
+        big[o:o + n] = np.frombuffer(eng.read_seq(i), dtype=np.uint8)
+        views.append(big[o:o + n])
+        o += n
+    codes, inv, low = eng.export_packed(pinned=True)
+    out = {}
+
+    def timed(body, label, nbytes):
+        body()                               # warm-up: allocates the second batch slot
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            body()
+        fence()
+        dt = (time.perf_counter() - t0) / steps
+        out[label] = {"windows_per_s": rows / dt, "ms_per_step": dt * 1e3, "pcie_bytes_per_step": nbytes}
+
+    def single_ascii():
+        eng.stage(views); eng.commit(); step()
+
+    def single_packed():
+        eng.stage_packed(codes, inv, low, lens); eng.commit(); step()
+
+    def pipelined():
+        eng.stage(views); step(); eng.commit()
+
+    timed(single_ascii, "single_job_ascii", total)
+    timed(single_packed, "single_job_packed", int(codes.nbytes + inv.nbytes + low.nbytes))
+    timed(pipelined, "pipelined_ascii", total)
+    out["note"] = ("host buffers page-locked; never part of `value`.  The profile needs all bases before the first window is "
+                   "scored, so a single job pays upload + scan; a stream of batches hides the upload behind the previous scan")
+    return out
+
+
+def self_launch(opts, argv):
+    """--gpus N without a launcher: become the launcher (no GPU call has been made yet) and relay the ranks' output."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opts.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -130,8 +196,13 @@ def main():
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="scale every scaffold length of the shard (testing only; 1.0 = the named workload)")
     ap.add_argument("--cpu-windows", type=int, default=150, help="windows in the CPU-baseline sample, ~0.1 s each (0 = skip)")
-    opts = ap.parse_args()
+    ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive measurements")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only (gloo, no GPU): proves the N-rank launch path; rank 0 prints {dry_run, world}")
+    opts = ap.parse_args(argv)
 
+    if opts.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(opts, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +211,21 @@ def main():
                          % (opts.gpus, world, opts.gpus))
     import torch
     dist = None
+    if opts.dry_run:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            dist.barrier()
+            seen = int(t.item())
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "world": world, "ranks_seen": seen}), flush=True)
+        return
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -189,26 +275,32 @@ def main():
     else:
         rows_all, bases_all, cand_all = float(rows), float(total_bases), float(n_cand)
 
+    upload = None
+    if world == 1 and not opts.no_upload:
+        upload = upload_inclusive(eng, lens, step, fence, opts.steps, rows)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / opts.steps
         scan_avg = sum(scan_ms) / len(scan_ms)
         # algorithmic bytes of one scan launch: 2-bit bases once, 40 B per emitted row, genome table once
         b_alg = 0.25 * total_bases + 40.0 * rows + 8.0 * sum(4 ** x for x in range(KMIN, KMAX + 1))
         achieved = b_alg / (scan_avg * 1e-3) / 1e9
-        issue = {}
-        traffic = None      # HBM bytes per scan launch from PMC counters (collected offline with rocprofv3, same workload)
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        width, handed8, handed16 = eng.scan_stat()
+        traffic, binding, pmc_src = None, None, None
+        # HBM traffic and issue counters: rocprofv3 --pmc passes of THIS workload, collected offline (separate runs, never
+        # combined with tracing) and committed; valid only for the same shard and the same kernel
+        tpath = os.path.join(ROOT, "profiles", "r2_pmc_bench.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("workload_bases_per_gpu") == total_bases and tj.get("candidate_windows_per_gpu") == n_cand:
-                traffic = tj["hbm_bytes_per_launch"]
-                issue = {k: tj[k] for k in ("SQ_INSTS_VALU_per_launch", "SQ_ACTIVE_INST_ANY_over_SQ_WAVE_CYCLES",
-                                            "waves_per_simd") if k in tj}
+                pmc_src = "profiles/r2_pmc_bench.json (offline rocprofv3 --pmc passes of this workload; not measured in this run)"
+                traffic = tj.get("hbm_bytes_per_launch")
+                binding = tj.get("binding")
         out = {
             "metric": "windows/sec (k=1..8, w=5kb, s=1kb)", "value": rows_all / (elapsed / opts.steps),
             "unit": "windows/s", "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16 counts + f64 scores", "data": "synthetic",
+            "dtype": "u8/u4 counts + f64 scores", "data": "synthetic",
             "config": {"workload": "C5 shape (GRCh38-like synthetic, 24 chromosome-scale + 400 small scaffolds, 7% N), "
                                    "one 1/8 LPT shard per GPU (N=8 is the full 3.1 Gb job), k=1..8 w=5000 i=1000; "
                                    "step = genome profile + all-reduce + window scan, inputs packed and resident in HBM",
@@ -218,11 +310,15 @@ def main():
             "windowed_gbases_per_s": rows_all * W / (elapsed / opts.steps) / 1e9,      # rows x w: bases looked at, overlap counted
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
             "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
+            "scan_counter_width": {"bulk_bits": width, "windows_handed_to_8bit": handed8, "windows_handed_to_16bit": handed16},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_kernel", "algorithmic_bytes_per_launch": b_alg, "issue_counters": issue,
-                         "note": "the path is not HBM-limited at any plausible rate (290 B/window); what binds is VALU issue "
-                                 "(FP64 scoring) + random LDS access + barrier waits - see DESIGN.md"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
+                         "kernel": "scan8_kernel (+ its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them)",
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
+                                 "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding`"},
+            "binding": binding,
+            "upload": upload,
         }
         if opts.cpu_windows > 0:
             cb, worst, np_line, c_line = cpu_baseline(eng, lens[0], opts.cpu_windows)

@@ -24,6 +24,11 @@ SYMBOLS = [
     ("frisk_last_error", C.c_char_p, [_P]),
     ("frisk_profile_len", C.c_int64, [_P]),
     ("frisk_seq_load", C.c_int, [_P, C.POINTER(C.c_char_p), _I64P, C.c_int32]),
+    ("frisk_seq_stage", C.c_int, [_P, C.POINTER(C.c_void_p), _I64P, C.c_int32]),
+    ("frisk_seq_stage_packed", C.c_int, [_P, _P, _P, _P, _I64P, C.c_int32]),
+    ("frisk_seq_commit", C.c_int, [_P]),
+    ("frisk_seq_export_packed", C.c_int, [_P, _P, _P, _P]),
+    ("frisk_seq_set_names", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int32]),
     ("frisk_fasta_load", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32), _I64P]),
     ("frisk_seq_count", C.c_int32, [_P]),
     ("frisk_seq_name", C.c_char_p, [_P, C.c_int32]),

@@ -54,14 +54,25 @@ struct frisk_ctx {
     double ms[3] = {-1.0, -1.0, -1.0};
     std::string err;
 
-    // resident batch
-    int32_t n_seq = 0;
-    std::vector<int64_t> seq_off, seq_len;
-    std::vector<std::string> seq_name;
-    int64_t padded_len = 0;
-    bool have_seq = false;
-    DevBuf<uint8_t> d_ascii;
-    DevBuf<uint32_t> d_codes, d_inv, d_low;
+    // sequence batches: bat[cur] is the resident one; the other slot receives the next batch while the resident one is
+    // being scanned (frisk_seq_stage / frisk_seq_commit)
+    struct Batch {
+        int32_t n_seq = 0;
+        std::vector<int64_t> seq_off, seq_len;
+        std::vector<std::string> seq_name;
+        int64_t padded_len = 0;
+        bool have_seq = false;
+        DevBuf<uint8_t> d_ascii;
+        DevBuf<uint32_t> d_codes, d_inv, d_low;
+        void release() { d_ascii.release(); d_codes.release(); d_inv.release(); d_low.release(); }
+    };
+    Batch bat[2];
+    int cur = 0;
+    Batch& b() { return bat[cur]; }
+    const Batch& b() const { return bat[cur]; }
+    hipStream_t copy_stream = nullptr;      // uploads + packing of the staged batch
+    hipEvent_t staged_ev = nullptr;         // recorded behind the staged batch's last operation
+    bool staged = false;
 
     // profile
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
@@ -70,8 +81,11 @@ struct frisk_ctx {
     DevBuf<unsigned int> d_ovf_count;          // [0], [1]: their numbers
     int64_t scan_stat[3] = {0, 0, 0};          // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16
     DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
-    int64_t total_len = 0, ex_max = 0, nn_total = 0;
+    DevBuf<int64_t> d_meta;          // {totalLen, exMax, nnTotal} of the finalised profile, on the device
+    int64_t* h_meta = nullptr;       // page-locked mirror, valid after the stream has been synchronised
     bool profile_final = false;
+    bool ms_pending[3] = {false, false, false};     // events recorded, elapsed time not read yet (frisk_last_kernel_ms)
+    hipEvent_t evp0 = nullptr, evp1 = nullptr;      // profile_add kernel
 
     // scan plan + outputs
     DevBuf<ScafDesc> d_desc;
@@ -110,51 +124,73 @@ int grid_for(int64_t items, int per_block, int max_blocks) {
     return int(b);
 }
 
-// common tail of frisk_seq_load / frisk_seq_synth: allocate + pack
-int alloc_packed(frisk_ctx* c) {
-    const size_t w32 = size_t(c->padded_len / 32);
-    HIPC(c, c->d_codes.reserve(2 * w32 + 8));
-    HIPC(c, c->d_inv.reserve(w32 + 8));
-    HIPC(c, c->d_low.reserve(w32 + 8));
+// layout of a batch in padded coordinates (frisk_device.h): scaffold s at [off, off+len), then at least one PAD
+int layout_batch(frisk_ctx* c, frisk_ctx::Batch& B, const int64_t* lens, int32_t n_seq) {
+    if (n_seq < 0) return fail(c, FRISK_E_ARG, "n_seq < 0");
+    B.seq_off.assign(size_t(n_seq), 0);
+    B.seq_len.assign(lens, lens + n_seq);
+    B.seq_name.assign(size_t(n_seq), std::string());
+    int64_t pos = 0;
+    for (int32_t s = 0; s < n_seq; ++s) {
+        if (lens[s] < 0) return fail(c, FRISK_E_ARG, "negative scaffold length");
+        B.seq_off[size_t(s)] = pos;
+        pos += lens[s] + 1;                       // at least one PAD position after every scaffold
+    }
+    B.padded_len = (pos + 31) / 32 * 32;
+    if (B.padded_len == 0) B.padded_len = 32;
+    B.n_seq = n_seq;
+    B.have_seq = false;
+    return FRISK_OK;
+}
+int layout_batch(frisk_ctx* c, const int64_t* lens, int32_t n_seq) { return layout_batch(c, c->b(), lens, n_seq); }
+
+// packed arrays of a batch: allocate, and mark the words past the batch
+int alloc_packed(frisk_ctx* c, frisk_ctx::Batch& B, hipStream_t st) {
+    const size_t w32 = size_t(B.padded_len / 32);
+    HIPC(c, B.d_codes.reserve(2 * w32 + 8));
+    HIPC(c, B.d_inv.reserve(w32 + 8));
+    HIPC(c, B.d_low.reserve(w32 + 8));
     // tail words past the batch: codes 0, inv/low all ones (= PAD), so a run can never extend past the end
-    HIPC(c, hipMemsetAsync(c->d_codes.p + 2 * w32, 0, 8 * sizeof(uint32_t), c->stream));
-    HIPC(c, hipMemsetAsync(c->d_inv.p + w32, 0xFF, 8 * sizeof(uint32_t), c->stream));
-    HIPC(c, hipMemsetAsync(c->d_low.p + w32, 0xFF, 8 * sizeof(uint32_t), c->stream));
+    HIPC(c, hipMemsetAsync(B.d_codes.p + 2 * w32, 0, 8 * sizeof(uint32_t), st));
+    HIPC(c, hipMemsetAsync(B.d_inv.p + w32, 0xFF, 8 * sizeof(uint32_t), st));
+    HIPC(c, hipMemsetAsync(B.d_low.p + w32, 0xFF, 8 * sizeof(uint32_t), st));
+    return FRISK_OK;
+}
+int alloc_packed(frisk_ctx* c) { return alloc_packed(c, c->b(), c->stream); }
+
+// ASCII -> packed, on stream `st`, no host synchronisation
+int enqueue_pack(frisk_ctx* c, frisk_ctx::Batch& B, hipStream_t st) {
+    const int64_t w32 = B.padded_len / 32;
+    if (w32 > 0)
+        pack_kernel<<<grid_for(w32, 256, c->num_cu * 8), 256, 0, st>>>(B.d_ascii.p, w32, B.d_codes.p, B.d_inv.p, B.d_low.p);
+    HIPC(c, hipGetLastError());
     return FRISK_OK;
 }
 
+// common tail of frisk_seq_load / frisk_seq_synth / frisk_fasta_load: pack the resident batch, timed, synchronous
 int run_pack(frisk_ctx* c) {
-    const int64_t w32 = c->padded_len / 32;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
-    if (w32 > 0)
-        pack_kernel<<<grid_for(w32, 256, c->num_cu * 8), 256, 0, c->stream>>>(c->d_ascii.p, w32, c->d_codes.p,
-                                                                               c->d_inv.p, c->d_low.p);
-    HIPC(c, hipGetLastError());
+    int rc = enqueue_pack(c, c->b(), c->stream);
+    if (rc) return rc;
     HIPC(c, hipEventRecord(c->ev1, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     float ms = 0;
     HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->ms[2] = ms;
-    c->have_seq = true;
+    c->b().have_seq = true;
     c->plan_w = -1;
     return FRISK_OK;
 }
 
-int layout_batch(frisk_ctx* c, const int64_t* lens, int32_t n_seq) {
-    if (n_seq < 0) return fail(c, FRISK_E_ARG, "n_seq < 0");
-    c->seq_off.assign(size_t(n_seq), 0);
-    c->seq_len.assign(lens, lens + n_seq);
-    c->seq_name.assign(size_t(n_seq), std::string());
-    int64_t pos = 0;
-    for (int32_t s = 0; s < n_seq; ++s) {
-        if (lens[s] < 0) return fail(c, FRISK_E_ARG, "negative scaffold length");
-        c->seq_off[size_t(s)] = pos;
-        pos += lens[s] + 1;                       // at least one PAD position after every scaffold
-    }
-    c->padded_len = (pos + 31) / 32 * 32;
-    if (c->padded_len == 0) c->padded_len = 32;
-    c->n_seq = n_seq;
-    c->have_seq = false;
+// ASCII scaffolds -> B.d_ascii on stream `st` (asynchronous for page-locked sources)
+int enqueue_ascii_upload(frisk_ctx* c, frisk_ctx::Batch& B, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq,
+                         hipStream_t st) {
+    HIPC(c, B.d_ascii.reserve(size_t(B.padded_len)));
+    // PAD everywhere first: the gaps between scaffolds and the tail.  (One memset of the whole buffer costs 0.1 ms per 400 MB.)
+    HIPC(c, hipMemsetAsync(B.d_ascii.p, FRISK_PAD_BYTE, size_t(B.padded_len), st));
+    for (int32_t s = 0; s < n_seq; ++s)
+        if (lens[s] > 0)
+            HIPC(c, hipMemcpyAsync(B.d_ascii.p + B.seq_off[size_t(s)], seqs[s], size_t(lens[s]), hipMemcpyHostToDevice, st));
     return FRISK_OK;
 }
 
@@ -216,12 +252,10 @@ inline const char* tune_env(const char* name) {
 
 int build_genome_table(frisk_ctx* c) {
     const int64_t n = int64_t(1) << (2 * c->kmax);
-    const int64_t genome_space = c->total_len - c->nn_total;                    // L379
-    genome_ivom_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(c->d_sym.p, c->kmin, c->kmax, genome_space,
-                                                                          c->d_ig.p);
+    genome_ivom_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(c->d_sym.p, c->kmin, c->kmax, c->d_meta.p, c->d_ig.p);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
-    c->profile_final = true;
+    HIPC(c, hipMemcpyAsync(c->h_meta, c->d_meta.p, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    c->profile_final = true;        // in stream order: everything that follows on the context's stream sees the table
     return FRISK_OK;
 }
 
@@ -257,12 +291,18 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
         return fail(c, FRISK_E_HIP, std::string("libfrisk_hip is built for gfx950 only; device is ") + prop.gcnArchName);
     c->num_cu = prop.multiProcessorCount;
     HIPC(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPC(c, hipEventCreateWithFlags(&c->staged_ev, hipEventDisableTiming));
     HIPC(c, hipEventCreate(&c->ev0));
     HIPC(c, hipEventCreate(&c->ev1));
     HIPC(c, c->d_raw.reserve(size_t(c->nprof) + 4));
     HIPC(c, c->d_cnt.reserve(size_t(c->nprof) + 4));
     HIPC(c, c->d_sym.reserve(size_t(c->nprof)));
     HIPC(c, c->d_ig.reserve(size_t(1) << (2 * kmax)));
+    HIPC(c, c->d_meta.reserve(4));
+    HIPC(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_meta), 4 * sizeof(int64_t), hipHostMallocDefault));
+    HIPC(c, hipEventCreate(&c->evp0));
+    HIPC(c, hipEventCreate(&c->evp1));
     HIPC(c, hipMemsetAsync(c->d_raw.p, 0, (size_t(c->nprof) + 4) * sizeof(int64_t), c->stream));
     {   // range-reduction table of the scan kernel's logarithm (scan_kernel.h: log_tab_pos)
         double tab[2 * FRISK_LOGTAB_N];
@@ -294,11 +334,17 @@ void frisk_destroy(frisk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->d_ascii.release(); c->d_codes.release(); c->d_inv.release(); c->d_low.release();
+    c->bat[0].release(); c->bat[1].release();
     c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_logtab64.release(); c->d_logtab32.release(); c->d_rctab.release(); c->d_ovf_list.release(); c->d_ovf_list2.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
     c->o_ivom.release(); c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->staged_ev) (void)hipEventDestroy(c->staged_ev);
+    if (c->h_meta) (void)hipHostFree(c->h_meta);
+    if (c->evp0) (void)hipEventDestroy(c->evp0);
+    if (c->evp1) (void)hipEventDestroy(c->evp1);
+    c->d_meta.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -308,7 +354,7 @@ void frisk_destroy(frisk_ctx* c) {
 const char* frisk_last_error(const frisk_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int64_t frisk_profile_len(const frisk_ctx* c) { return c ? c->nprof : 0; }
 int64_t frisk_profile_raw_len(const frisk_ctx* c) { return c ? c->nprof + 4 : 0; }
-int64_t frisk_seq_padded_len(const frisk_ctx* c) { return (c && c->have_seq) ? c->padded_len : 0; }
+int64_t frisk_seq_padded_len(const frisk_ctx* c) { return (c && c->b().have_seq) ? c->b().padded_len : 0; }
 void* frisk_host_alloc(frisk_ctx* c, int64_t bytes) {
     if (!c || bytes <= 0) return nullptr;
     void* p = nullptr;
@@ -319,7 +365,16 @@ void* frisk_host_alloc(frisk_ctx* c, int64_t bytes) {
 void frisk_host_free(frisk_ctx* c, void* ptr) {
     if (c && ptr) { (void)hipSetDevice(c->device); (void)hipHostFree(ptr); }
 }
-double frisk_last_kernel_ms(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 3) ? c->ms[which] : -1.0; }
+double frisk_last_kernel_ms(const frisk_ctx* cc, int which) {
+    frisk_ctx* c = const_cast<frisk_ctx*>(cc);
+    if (!c || which < 0 || which >= 3) return -1.0;
+    if (which == 1 && c->ms_pending[1]) {           // the profile kernel's events are read on demand: no sync in profile_add
+        float ms = 0;
+        if (hipEventSynchronize(c->evp1) == hipSuccess && hipEventElapsedTime(&ms, c->evp0, c->evp1) == hipSuccess) c->ms[1] = ms;
+        c->ms_pending[1] = false;
+    }
+    return c->ms[which];
+}
 
 // ------------------------------------------------------------------------------------- sequences
 int frisk_seq_load(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq) {
@@ -328,18 +383,15 @@ int frisk_seq_load(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens
     HIPC(c, hipSetDevice(c->device));
     int rc = layout_batch(c, lens, n_seq);
     if (rc) return rc;
-    HIPC(c, c->d_ascii.reserve(size_t(c->padded_len)));
     if (n_seq <= 64) {
-        HIPC(c, hipMemsetAsync(c->d_ascii.p, FRISK_PAD_BYTE, size_t(c->padded_len), c->stream));
-        for (int32_t s = 0; s < n_seq; ++s)
-            if (lens[s] > 0)
-                HIPC(c, hipMemcpyAsync(c->d_ascii.p + c->seq_off[size_t(s)], seqs[s], size_t(lens[s]),
-                                       hipMemcpyHostToDevice, c->stream));
+        rc = enqueue_ascii_upload(c, c->b(), seqs, lens, n_seq, c->stream);
+        if (rc) return rc;
     } else {            // many small scaffolds: assemble once on the host, one copy
-        std::vector<uint8_t> stage(size_t(c->padded_len), uint8_t(FRISK_PAD_BYTE));
+        HIPC(c, c->b().d_ascii.reserve(size_t(c->b().padded_len)));
+        std::vector<uint8_t> stage(size_t(c->b().padded_len), uint8_t(FRISK_PAD_BYTE));
         for (int32_t s = 0; s < n_seq; ++s)
-            if (lens[s] > 0) std::memcpy(stage.data() + c->seq_off[size_t(s)], seqs[s], size_t(lens[s]));
-        HIPC(c, hipMemcpyAsync(c->d_ascii.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
+            if (lens[s] > 0) std::memcpy(stage.data() + c->b().seq_off[size_t(s)], seqs[s], size_t(lens[s]));
+        HIPC(c, hipMemcpyAsync(c->b().d_ascii.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
     rc = alloc_packed(c);
@@ -409,10 +461,10 @@ int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t
     HIPC(c, hipSetDevice(c->device));
     int rc = layout_batch(c, lens.data(), int32_t(lens.size()));
     if (rc) return rc;
-    c->seq_name = names;
-    stage.resize(size_t(c->padded_len), uint8_t(FRISK_PAD_BYTE));          // tail padding up to a multiple of 32
-    HIPC(c, c->d_ascii.reserve(size_t(c->padded_len)));
-    HIPC(c, hipMemcpyAsync(c->d_ascii.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
+    c->b().seq_name = names;
+    stage.resize(size_t(c->b().padded_len), uint8_t(FRISK_PAD_BYTE));          // tail padding up to a multiple of 32
+    HIPC(c, c->b().d_ascii.reserve(size_t(c->b().padded_len)));
+    HIPC(c, hipMemcpyAsync(c->b().d_ascii.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     rc = alloc_packed(c);
     if (rc) return rc;
@@ -425,12 +477,83 @@ int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t
     return FRISK_OK;
 }
 
-int32_t frisk_seq_count(const frisk_ctx* c) { return (c && c->have_seq) ? c->n_seq : 0; }
+int32_t frisk_seq_count(const frisk_ctx* c) { return (c && c->b().have_seq) ? c->b().n_seq : 0; }
 const char* frisk_seq_name(const frisk_ctx* c, int32_t s) {
-    return (c && c->have_seq && s >= 0 && s < c->n_seq) ? c->seq_name[size_t(s)].c_str() : "";
+    return (c && c->b().have_seq && s >= 0 && s < c->b().n_seq) ? c->b().seq_name[size_t(s)].c_str() : "";
 }
 int64_t frisk_seq_len(const frisk_ctx* c, int32_t s) {
-    return (c && c->have_seq && s >= 0 && s < c->n_seq) ? c->seq_len[size_t(s)] : -1;
+    return (c && c->b().have_seq && s >= 0 && s < c->b().n_seq) ? c->b().seq_len[size_t(s)] : -1;
+}
+
+// ---- double-buffered residency: upload the NEXT batch while the resident one is being profiled / scanned ----------
+int frisk_seq_stage(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq) {
+    if (!c) return FRISK_E_ARG;
+    if (n_seq > 0 && (!seqs || !lens)) return fail(c, FRISK_E_ARG, "null sequence table");
+    HIPC(c, hipSetDevice(c->device));
+    frisk_ctx::Batch& B = c->bat[c->cur ^ 1];
+    c->staged = false;
+    int rc = layout_batch(c, B, lens, n_seq);
+    if (rc) return rc;
+    rc = enqueue_ascii_upload(c, B, seqs, lens, n_seq, c->copy_stream);
+    if (rc) return rc;
+    rc = alloc_packed(c, B, c->copy_stream);
+    if (rc) return rc;
+    rc = enqueue_pack(c, B, c->copy_stream);
+    if (rc) return rc;
+    HIPC(c, hipEventRecord(c->staged_ev, c->copy_stream));
+    c->staged = true;
+    return FRISK_OK;
+}
+
+int frisk_seq_stage_packed(frisk_ctx* c, const uint32_t* codes, const uint32_t* inv, const uint32_t* low, const int64_t* lens,
+                           int32_t n_seq) {
+    if (!c) return FRISK_E_ARG;
+    if (!codes || !inv || !low || (n_seq > 0 && !lens)) return fail(c, FRISK_E_ARG, "null packed arrays");
+    HIPC(c, hipSetDevice(c->device));
+    frisk_ctx::Batch& B = c->bat[c->cur ^ 1];
+    c->staged = false;
+    int rc = layout_batch(c, B, lens, n_seq);
+    if (rc) return rc;
+    rc = alloc_packed(c, B, c->copy_stream);
+    if (rc) return rc;
+    const size_t w32 = size_t(B.padded_len / 32);
+    HIPC(c, hipMemcpyAsync(B.d_codes.p, codes, 2 * w32 * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIPC(c, hipMemcpyAsync(B.d_inv.p, inv, w32 * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIPC(c, hipMemcpyAsync(B.d_low.p, low, w32 * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIPC(c, hipEventRecord(c->staged_ev, c->copy_stream));
+    c->staged = true;
+    return FRISK_OK;
+}
+
+int frisk_seq_commit(frisk_ctx* c) {
+    if (!c) return FRISK_E_ARG;
+    if (!c->staged) return fail(c, FRISK_E_STATE, "frisk_seq_commit: no staged batch");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamWaitEvent(c->stream, c->staged_ev, 0));   // the compute stream waits on the device; the host does not
+    c->cur ^= 1;
+    c->b().have_seq = true;
+    c->staged = false;
+    c->plan_w = -1;
+    return FRISK_OK;
+}
+
+int frisk_seq_export_packed(frisk_ctx* c, uint32_t* codes, uint32_t* inv, uint32_t* low) {
+    if (!c || !codes || !inv || !low) return FRISK_E_ARG;
+    if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t w32 = size_t(c->b().padded_len / 32);
+    HIPC(c, hipMemcpyAsync(codes, c->b().d_codes.p, 2 * w32 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(inv, c->b().d_inv.p, w32 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(low, c->b().d_low.p, w32 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FRISK_OK;
+}
+
+int frisk_seq_set_names(frisk_ctx* c, const char* const* names, int32_t n_seq) {
+    if (!c || (n_seq > 0 && !names)) return FRISK_E_ARG;
+    if (!c->b().have_seq || n_seq != c->b().n_seq) return fail(c, FRISK_E_ARG, "frisk_seq_set_names: one name per resident scaffold");
+    for (int32_t s = 0; s < n_seq; ++s) c->b().seq_name[size_t(s)] = names[s] ? names[s] : "";
+    return FRISK_OK;
 }
 
 int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t seed, double island_frac,
@@ -440,8 +563,8 @@ int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t s
     HIPC(c, hipSetDevice(c->device));
     int rc = layout_batch(c, lens, n_seq);
     if (rc) return rc;
-    HIPC(c, c->d_ascii.reserve(size_t(c->padded_len)));
-    HIPC(c, hipMemsetAsync(c->d_ascii.p, FRISK_PAD_BYTE, size_t(c->padded_len), c->stream));
+    HIPC(c, c->b().d_ascii.reserve(size_t(c->b().padded_len)));
+    HIPC(c, hipMemsetAsync(c->b().d_ascii.p, FRISK_PAD_BYTE, size_t(c->b().padded_len), c->stream));
     SynthTables tabs;
     synth_make_tables(seed, tabs);
     const uint32_t thr_island = synth_frac_to_u32(island_frac), thr_nbig = synth_frac_to_u32(n_frac * 0.8),
@@ -449,7 +572,7 @@ int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t s
     for (int32_t s = 0; s < n_seq; ++s) {
         if (lens[s] <= 0) continue;
         const int64_t nblk = (lens[s] + SYNTH_BLOCK - 1) / SYNTH_BLOCK;
-        synth_kernel<<<grid_for(nblk, 64, 1 << 20), 64, 0, c->stream>>>(c->d_ascii.p + c->seq_off[size_t(s)], lens[s],
+        synth_kernel<<<grid_for(nblk, 64, 1 << 20), 64, 0, c->stream>>>(c->b().d_ascii.p + c->b().seq_off[size_t(s)], lens[s],
                                                                        seed, uint32_t(s), tabs, thr_island, thr_nbig,
                                                                        thr_nsmall, thr_low);
         HIPC(c, hipGetLastError());
@@ -461,15 +584,15 @@ int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t s
 
 int frisk_seq_read(frisk_ctx* c, int32_t s, int64_t offset, int64_t n, uint8_t* out) {
     if (!c || !out) return FRISK_E_ARG;
-    if (!c->have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
-    if (s < 0 || s >= c->n_seq) return fail(c, FRISK_E_ARG, "sequence index out of range");
-    if (offset < 0 || n < 0 || offset + n > c->seq_len[size_t(s)]) return fail(c, FRISK_E_ARG, "range outside the scaffold");
+    if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
+    if (s < 0 || s >= c->b().n_seq) return fail(c, FRISK_E_ARG, "sequence index out of range");
+    if (offset < 0 || n < 0 || offset + n > c->b().seq_len[size_t(s)]) return fail(c, FRISK_E_ARG, "range outside the scaffold");
     if (n == 0) return FRISK_OK;
     HIPC(c, hipSetDevice(c->device));
     DevBuf<uint8_t> tmp;
     HIPC(c, tmp.reserve(size_t(n)));
-    unpack_kernel<<<grid_for(n, 256, c->num_cu * 8), 256, 0, c->stream>>>(c->d_codes.p, c->d_inv.p, c->d_low.p,
-                                                                           c->seq_off[size_t(s)] + offset, n, tmp.p);
+    unpack_kernel<<<grid_for(n, 256, c->num_cu * 8), 256, 0, c->stream>>>(c->b().d_codes.p, c->b().d_inv.p, c->b().d_low.p,
+                                                                           c->b().seq_off[size_t(s)] + offset, n, tmp.p);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp.p, size_t(n), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -483,16 +606,15 @@ int frisk_profile_reset(frisk_ctx* c) {
     if (!c) return FRISK_E_ARG;
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemsetAsync(c->d_raw.p, 0, (size_t(c->nprof) + 4) * sizeof(int64_t), c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
     c->profile_final = false;
     return FRISK_OK;
 }
 
 int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
     if (!c) return FRISK_E_ARG;
-    if (!c->have_seq) return fail(c, FRISK_E_STATE, "frisk_profile_add: no resident sequence batch");
-    if (p0 < 0 && p1 < 0) { p0 = 0; p1 = c->padded_len; }
-    if (p0 < 0 || p1 > c->padded_len || p0 > p1) return fail(c, FRISK_E_ARG, "position range outside the batch");
+    if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "frisk_profile_add: no resident sequence batch");
+    if (p0 < 0 && p1 < 0) { p0 = 0; p1 = c->b().padded_len; }
+    if (p0 < 0 || p1 > c->b().padded_len || p0 > p1) return fail(c, FRISK_E_ARG, "position range outside the batch");
     HIPC(c, hipSetDevice(c->device));
     c->profile_final = false;
     // order-K table privatised in LDS (u32): split in two halves at K = 8 (256 KiB does not fit a CU)
@@ -506,21 +628,18 @@ int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
     int64_t nchunks = std::min<int64_t>(std::max<int64_t>(1, span / 65536), int64_t(c->num_cu) * FRISK_PROF_WG_PER_CU / halves);
     const int64_t chunk_len = (nwords + nchunks - 1) / std::max<int64_t>(nchunks, 1);   // in words
     nchunks = chunk_len > 0 ? (nwords + chunk_len - 1) / chunk_len : 0;
-    HIPC(c, hipEventRecord(c->ev0, c->stream));
+    HIPC(c, hipEventRecord(c->evp0, c->stream));
     if (span > 0) {
         auto raw = reinterpret_cast<unsigned long long*>(c->d_raw.p);
         HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(profile_add_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max<size_t>(lds, 16))));
         profile_add_kernel<<<int(nchunks) * halves, FRISK_PROF_NT, std::max<size_t>(lds, 16), c->stream>>>(
-            c->d_codes.p, c->d_inv.p, c->d_low.p, p0, p1, c->kmin, c->kmax, mask_host ? 1 : 0, int(c->nprof), halves,
+            c->b().d_codes.p, c->b().d_inv.p, c->b().d_low.p, p0, p1, c->kmin, c->kmax, mask_host ? 1 : 0, int(c->nprof), halves,
             chunk_len, raw);
     }
     HIPC(c, hipGetLastError());
-    HIPC(c, hipEventRecord(c->ev1, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    float ms = 0;
-    HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->ms[1] = ms;
+    HIPC(c, hipEventRecord(c->evp1, c->stream));
+    c->ms_pending[1] = true;        // asynchronous: the elapsed time is read when frisk_last_kernel_ms(1) asks for it
     return FRISK_OK;
 }
 
@@ -566,18 +685,9 @@ int frisk_profile_finalize(frisk_ctx* c) {
     }
     symmetrize_kernel<<<grid_for(c->nprof, 256, 1 << 20), 256, 0, c->stream>>>(c->d_cnt.p, c->d_sym.p, c->kmin, c->kmax);
     HIPC(c, hipGetLastError());
-    // metadata of L356-359: totalLen, exMax = K-mer start positions that were NOT counted, nnTotal
-    std::vector<int64_t> top(size_t(1) << (2 * c->kmax));
-    int64_t tail[4];
-    HIPC(c, hipMemcpyAsync(top.data(), c->d_cnt.p + table_offset(c->kmin, c->kmax), top.size() * 8,
-                           hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(tail, c->d_raw.p + c->nprof, 4 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    int64_t counted = 0;
-    for (int64_t v : top) counted += v;
-    c->total_len = tail[0];
-    c->ex_max = tail[1] - counted;
-    c->nn_total = tail[2];
+    // metadata of L356-359 (totalLen, exMax, nnTotal): computed on the device, mirrored to the host asynchronously
+    profile_meta_kernel<<<1, 1024, 0, c->stream>>>(c->d_cnt.p, c->d_raw.p + c->nprof, c->kmin, c->kmax, c->d_meta.p);
+    HIPC(c, hipGetLastError());
     return build_genome_table(c);
 }
 
@@ -585,30 +695,29 @@ int frisk_profile_get(frisk_ctx* c, int64_t* sym, int64_t* total_len, int64_t* e
     if (!c) return FRISK_E_ARG;
     if (!c->profile_final) return fail(c, FRISK_E_STATE, "profile not finalised");
     HIPC(c, hipSetDevice(c->device));
-    if (sym) {
-        HIPC(c, hipMemcpyAsync(sym, c->d_sym.p, size_t(c->nprof) * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
-    }
-    if (total_len) *total_len = c->total_len;
-    if (ex_max) *ex_max = c->ex_max;
-    if (nn_total) *nn_total = c->nn_total;
+    if (sym) HIPC(c, hipMemcpyAsync(sym, c->d_sym.p, size_t(c->nprof) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (total_len) *total_len = c->h_meta[0];
+    if (ex_max) *ex_max = c->h_meta[1];
+    if (nn_total) *nn_total = c->h_meta[2];
     return FRISK_OK;
 }
 
 int frisk_profile_set(frisk_ctx* c, const int64_t* sym, int64_t total_len, int64_t ex_max, int64_t nn_total) {
     if (!c || !sym) return FRISK_E_ARG;
     HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));                   // h_meta may still be the target of an earlier mirror copy
     HIPC(c, hipMemcpyAsync(c->d_sym.p, sym, size_t(c->nprof) * 8, hipMemcpyHostToDevice, c->stream));
-    c->total_len = total_len;
-    c->ex_max = ex_max;
-    c->nn_total = nn_total;
+    c->h_meta[0] = total_len; c->h_meta[1] = ex_max; c->h_meta[2] = nn_total;
+    HIPC(c, hipMemcpyAsync(c->d_meta.p, c->h_meta, 3 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));                   // `sym` is the caller's: the copy must have left it
     return build_genome_table(c);
 }
 
 // --------------------------------------------------------------------------------------- phase B
 int frisk_scan_plan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t* n_candidates) {
     if (!c) return FRISK_E_ARG;
-    if (!c->have_seq) return fail(c, FRISK_E_STATE, "frisk_scan_plan: no resident sequence batch");
+    if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "frisk_scan_plan: no resident sequence batch");
     if (w < 1 || inc < 1) return fail(c, FRISK_E_ARG, "window length and increment must be >= 1");
     const bool all = (flags & FRISK_SCAN_SCAFFOLDS_ALL) != 0;
     if (c->plan_w == w && c->plan_inc == inc && ((c->plan_flags ^ flags) & FRISK_SCAN_SCAFFOLDS_ALL) == 0) {
@@ -616,20 +725,20 @@ int frisk_scan_plan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_
         return FRISK_OK;
     }
     HIPC(c, hipSetDevice(c->device));
-    c->h_desc.assign(size_t(c->n_seq) + 1, ScafDesc());
+    c->h_desc.assign(size_t(c->b().n_seq) + 1, ScafDesc());
     int64_t cand = 0, maxwin = 0;
-    for (int32_t s = 0; s < c->n_seq; ++s) {
+    for (int32_t s = 0; s < c->b().n_seq; ++s) {
         ScafDesc& d = c->h_desc[size_t(s)];
-        d.off = c->seq_off[size_t(s)];
-        d.size = c->seq_len[size_t(s)];
+        d.off = c->b().seq_off[size_t(s)];
+        d.size = c->b().seq_len[size_t(s)];
         d.cand0 = cand;
         plan_scaffold(d.size, w, inc, all, d.ncand, d.kind);
         d.pad_ = 0;
         if (d.ncand > 0) maxwin = std::max<int64_t>(maxwin, d.kind == 1 ? d.size : w);
         cand += d.ncand;
     }
-    ScafDesc& sentinel = c->h_desc[size_t(c->n_seq)];       // keeps the binary search in range
-    sentinel.off = c->padded_len; sentinel.size = 0; sentinel.cand0 = cand; sentinel.ncand = 0; sentinel.kind = 0;
+    ScafDesc& sentinel = c->h_desc[size_t(c->b().n_seq)];       // keeps the binary search in range
+    sentinel.off = c->b().padded_len; sentinel.size = 0; sentinel.cand0 = cand; sentinel.ncand = 0; sentinel.kind = 0;
     sentinel.pad_ = 0;
     if (maxwin > 0x7FFFFFFF) return fail(c, FRISK_E_ARG, "a window longer than 2^31-1 bases");
     HIPC(c, c->d_desc.reserve(c->h_desc.size()));
@@ -677,9 +786,9 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
 
     ScanParams P;
-    P.codes = c->d_codes.p; P.inv = c->d_inv.p; P.low = c->d_low.p;
+    P.codes = c->b().d_codes.p; P.inv = c->b().d_inv.p; P.low = c->b().d_low.p;
     P.descs = c->d_desc.p; P.ig = c->d_ig.p; P.log_tab = c->d_logtab.p; P.log_tab64 = c->d_logtab64.p; P.log_tab32 = c->d_logtab32.p;
-    P.n_desc = c->n_seq + 1;
+    P.n_desc = c->b().n_seq + 1;
     P.kmin = c->kmin; P.kmax = c->kmax; P.w = w; P.inc = inc; P.flags = flags; P.c0 = c0; P.c1 = c1;
     P.orphan_cap = int32_t(c->plan_maxwin / 8 + 2);
     P.nprof = int32_t(c->nprof);

@@ -198,10 +198,34 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(const int64_t* __restri
 // reference's operation order (it is computed once; the scan kernel uses the closed form on the window side).
 // ------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
+// metadata of L356-359 on the device: meta[0] = totalLen, meta[1] = exMax = the K-mer start positions that were NOT counted,
+// meta[2] = nnTotal.  `cnt` = marginalised forward counts (profile layout), `raw_tail` = {totalLen, K-mer start positions,
+// nnTotal} summed over positions.  One workgroup; the order-K table has at most 4^8 entries.
+__global__ __launch_bounds__(1024) void profile_meta_kernel(const int64_t* __restrict__ cnt, const int64_t* __restrict__ raw_tail,
+                                                             int kmin, int kmax, int64_t* __restrict__ meta) {
+    __shared__ long long part[16];
+    const int64_t n = int64_t(1) << (2 * kmax);
+    const int64_t* top = cnt + table_offset(kmin, kmax);
+    long long s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += top[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long counted = 0;
+        for (int w = 0; w < int(blockDim.x >> 6); ++w) counted += part[w];
+        meta[0] = raw_tail[0];
+        meta[1] = raw_tail[1] - counted;
+        meta[2] = raw_tail[2];
+    }
+}
+
+// `meta` (device): {totalLen, exMax, nnTotal}; genomeSpace = totalLen - nnTotal (L379)
 __global__ __launch_bounds__(256) void genome_ivom_kernel(const int64_t* __restrict__ sym, int kmin, int kmax,
-                                                           int64_t genome_space, double* __restrict__ ig) {
+                                                           const int64_t* __restrict__ meta, double* __restrict__ ig) {
     const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= (int64_t(1) << (2 * kmax))) return;
+    const int64_t genome_space = meta[0] - meta[2];
     unsigned long long W = 0;
     double I = 0.0;
     bool bad = false;

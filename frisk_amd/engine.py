@@ -116,6 +116,52 @@ class Engine:
         self.n_seq = n
         self.seq_lens = [len(b) for b in bufs]
 
+    def host_array(self, name, n, dtype=np.uint8):
+        """numpy array in page-locked host memory owned by this engine (uploads from it are asynchronous)."""
+        return self._pinned_array("host:" + name, n, dtype)
+
+    @staticmethod
+    def _as_u8(s):
+        if isinstance(s, np.ndarray):
+            return np.ascontiguousarray(s, dtype=np.uint8)
+        if isinstance(s, str):
+            s = s.encode("ascii")
+        return np.frombuffer(bytes(s), dtype=np.uint8)
+
+    def stage(self, seqs):
+        """Start uploading + packing the NEXT batch on the copy stream while the resident one is in use; `commit()` makes it
+        resident.  Asynchronous when the scaffolds are views of `host_array` buffers; keep them alive until after commit."""
+        arrs = [self._as_u8(s) for s in seqs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        lens = (C.c_int64 * max(n, 1))(*[a.size for a in arrs])
+        self._check(self._lib.frisk_seq_stage(self._ctx, ptrs, lens, n))
+        self._staged = (arrs, [int(a.size) for a in arrs])
+
+    def stage_packed(self, codes, inv, low, lens):
+        """The same from the three bit-packed arrays (library layout, as `export_packed` returns them): 0.5 B/base."""
+        lens = [int(x) for x in lens]
+        arr = (C.c_int64 * max(len(lens), 1))(*lens)
+        keep = [np.ascontiguousarray(a, dtype=np.uint32) for a in (codes, inv, low)]
+        self._check(self._lib.frisk_seq_stage_packed(self._ctx, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), arr, len(lens)))
+        self._staged = (keep, lens)
+
+    def commit(self, names=None):
+        self._check(self._lib.frisk_seq_commit(self._ctx))
+        self._keepalive, lens = self._staged
+        self.n_seq, self.seq_lens = len(lens), list(lens)
+        if names is not None:
+            arr = (C.c_char_p * max(len(names), 1))(*[n.encode("ascii", "replace") for n in names])
+            self._check(self._lib.frisk_seq_set_names(self._ctx, arr, len(names)))
+
+    def export_packed(self, pinned=False):
+        """(codes, inv, low) of the resident batch as uint32 arrays (2P/32, P/32, P/32 words; P = padded_len)."""
+        w32 = self.padded_len // 32
+        new = (lambda nm, n: self.host_array(nm, n, np.uint32)) if pinned else (lambda nm, n: np.empty(n, np.uint32))
+        codes, inv, low = new("codes", 2 * w32), new("inv", w32), new("low", w32)
+        self._check(self._lib.frisk_seq_export_packed(self._ctx, _ptr(codes), _ptr(inv), _ptr(low)))
+        return codes, inv, low
+
     def load_fasta(self, path):
         """Parse a FASTA / FASTA.gz file in the library (no Python per-line loop) and make its records resident.
         Returns the record names."""

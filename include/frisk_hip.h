@@ -67,6 +67,22 @@ int64_t frisk_profile_len(const frisk_ctx* ctx);      /* sum_{x=kmin..kmax} 4^x 
  * next load.  Empty scaffolds (len 0) are allowed. */
 int frisk_seq_load(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq);
 
+/* Double-buffered residency - the "streamed to HBM" of the north star.  frisk_seq_stage uploads and packs the NEXT batch on
+ * a second HIP stream while the resident batch is being profiled / scanned; frisk_seq_commit makes it the resident batch
+ * (the compute stream waits for the upload on the device, the host does not block).  The copies are asynchronous when the
+ * source buffers are page-locked (frisk_host_alloc); the caller keeps them alive until the next synchronising call
+ * (frisk_scan, frisk_profile_add, ...) after the commit.  frisk_seq_stage_packed takes the three bit-packed arrays in the
+ * library's own layout (as frisk_seq_export_packed returns them for the same `lens`): 0.5 bytes per base over PCIe instead
+ * of 1, and no parsing - the sequence-cache path of the CLI. */
+int frisk_seq_stage(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq);
+int frisk_seq_stage_packed(frisk_ctx* ctx, const uint32_t* codes, const uint32_t* inv, const uint32_t* low,
+                           const int64_t* lens, int32_t n_seq);
+int frisk_seq_commit(frisk_ctx* ctx);
+/* Packed arrays of the resident batch: codes 2 * P / 32 words, inv and low P / 32 words each, P = frisk_seq_padded_len(). */
+int frisk_seq_export_packed(frisk_ctx* ctx, uint32_t* codes, uint32_t* inv, uint32_t* low);
+/* Record names for a batch that did not come from frisk_fasta_load (e.g. from the sequence cache). */
+int frisk_seq_set_names(frisk_ctx* ctx, const char* const* names, int32_t n_seq);
+
 /* Native FASTA reader: parse `path` (plain or gzip) with the record semantics of the reference's iterFasta
  * (L139-164: name = first whitespace-delimited token of the header with '>' stripped from both ends, lines stripped of
  * surrounding whitespace, blank lines skipped, case preserved) straight into the upload layout, and make its records
