@@ -30,6 +30,8 @@ SYMBOLS = [
     ("frisk_seq_export_packed", C.c_int, [_P, _P, _P, _P]),
     ("frisk_seq_set_names", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int32]),
     ("frisk_fasta_load", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32), _I64P]),
+    ("frisk_fasta_load_shard", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_int32), _I64P, _I64P, _I64P]),
     ("frisk_seq_count", C.c_int32, [_P]),
     ("frisk_seq_name", C.c_char_p, [_P, C.c_int32]),
     ("frisk_seq_len", C.c_int64, [_P, C.c_int32]),
@@ -51,6 +53,8 @@ SYMBOLS = [
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("frisk_scan_ivom", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     ("frisk_last_scan_stat", C.c_int64, [_P, C.c_int]),
+    ("frisk_format_rows", C.c_void_p, [C.c_int64, C.POINTER(C.c_char_p), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64P]),
+    ("frisk_free", None, [_P]),
     ("frisk_host_alloc", C.c_void_p, [_P, C.c_int64]),
     ("frisk_host_free", None, [_P, _P]),
     ("frisk_last_kernel_ms", C.c_double, [_P, C.c_int]),

@@ -19,6 +19,7 @@
 #include "scan8_kernel.h"
 #include "scan_big_kernel.h"
 #include "synth_kernel.h"
+#include "table_text.h"
 
 #ifndef FRISK_K8_WIDTH
 #define FRISK_K8_WIDTH 0            // order-8 counters of the default K = 8 path (scan8_kernel.h): 0 = adaptive 4/8 bits, 4, 8, 16 = off
@@ -64,6 +65,23 @@ struct frisk_ctx {
         bool have_seq = false;
         DevBuf<uint8_t> d_ascii;
         DevBuf<uint32_t> d_codes, d_inv, d_low;
+        // A TILED batch (frisk_fasta_load_shard) holds, per scaffold, only the bases one rank needs: the windows of its
+        // candidate range plus the positions whose k-mers it counts.  "Sequences" of the layout above are then tiles.
+        struct Tile {
+            int32_t scaf;               // index of the scaffold in the FASTA (what seq_index reports)
+            int64_t size;               // length of the whole scaffold
+            int64_t base0;              // position inside the scaffold of the tile's first base
+            int64_t j0, ncand;          // first window index inside the scaffold and number of windows scored here
+            int32_t kind;               // as ScafDesc::kind
+            int64_t own0, own1;         // [own0, own1): scaffold positions whose k-mers THIS rank counts in phase A
+        };
+        bool tiled = false;
+        std::vector<Tile> tiles;
+        int32_t tile_w = 0, tile_inc = 0;
+        uint32_t tile_flags = 0;
+        int64_t cand_begin = 0, cand_end = 0;       // the rank's range of the job's candidate numbering
+        std::vector<std::string> g_name;            // all records of the FASTA
+        std::vector<int64_t> g_len;
         void release() { d_ascii.release(); d_codes.release(); d_inv.release(); d_low.release(); }
     };
     Batch bat[2];
@@ -140,6 +158,8 @@ int layout_batch(frisk_ctx* c, frisk_ctx::Batch& B, const int64_t* lens, int32_t
     if (B.padded_len == 0) B.padded_len = 32;
     B.n_seq = n_seq;
     B.have_seq = false;
+    B.tiled = false;
+    B.tiles.clear(); B.g_name.clear(); B.g_len.clear();
     return FRISK_OK;
 }
 int layout_batch(frisk_ctx* c, const int64_t* lens, int32_t n_seq) { return layout_batch(c, c->b(), lens, n_seq); }
@@ -257,6 +277,125 @@ int build_genome_table(frisk_ctx* c) {
     HIPC(c, hipMemcpyAsync(c->h_meta, c->d_meta.p, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     c->profile_final = true;        // in stream order: everything that follows on the context's stream sees the table
     return FRISK_OK;
+}
+
+// [lo, hi) of the rank-th of `world` near-equal contiguous parts of range(n)
+void split_range(int64_t n, int rank, int world, int64_t& lo, int64_t& hi) {
+    const int64_t base = n / world, extra = n % world;
+    lo = rank * base + std::min<int64_t>(rank, extra);
+    hi = lo + base + (rank < extra ? 1 : 0);
+}
+
+// Window-tile sharding: the job's candidate windows are numbered in output order over ALL scaffolds and cut
+// into `world` contiguous ranges; a rank keeps, per scaffold, the bases of its windows - [j0*i, (j1-1)*i + w), reaching back
+// to size-w where its range includes the scaffold's jumpback windows (L230-243) - and counts (phase A) the k-mers that start
+// in [j0*i, j1*i), or up to the scaffold's end behind its last window, so that every base of the genome is counted by
+// exactly one rank; K-1 bases beyond that range are kept for the words that start in it.  Scaffolds without windows go to
+// the rank whose range holds their position in the numbering.
+std::vector<frisk_ctx::Batch::Tile> plan_tiles(const std::vector<int64_t>& lens, int32_t w, int32_t inc, bool all, int kmax,
+                                               int rank, int world, int64_t& c0, int64_t& c1) {
+    std::vector<int64_t> ncand(lens.size()), first(lens.size());
+    std::vector<int32_t> kind(lens.size());
+    int64_t total = 0;
+    for (size_t s = 0; s < lens.size(); ++s) {
+        plan_scaffold(lens[s], w, inc, all, ncand[s], kind[s]);
+        first[s] = total;
+        total += ncand[s];
+    }
+    split_range(total, rank, world, c0, c1);
+    std::vector<frisk_ctx::Batch::Tile> tiles;
+    for (size_t s = 0; s < lens.size(); ++s) {
+        const int64_t size = lens[s];
+        const int64_t ja = std::max<int64_t>(c0, first[s]) - first[s], jb = std::min<int64_t>(c1, first[s] + ncand[s]) - first[s];
+        frisk_ctx::Batch::Tile t;
+        t.scaf = int32_t(s); t.size = size; t.kind = kind[s];
+        if (jb > ja) {
+            t.j0 = ja; t.ncand = jb - ja;
+            if (kind[s] == 1) { t.base0 = 0; t.own0 = 0; t.own1 = size; tiles.push_back(t); continue; }
+            int64_t a = ja * inc;
+            if ((jb - 1) * inc + w > size) a = std::min<int64_t>(a, std::max<int64_t>(0, size - w));    // jumpback windows
+            t.base0 = a;
+            t.own0 = ja * inc;
+            t.own1 = (jb == ncand[s]) ? size : jb * inc;
+            tiles.push_back(t);             // (what it keeps resident ends at tile_end())
+        } else if (ncand[s] == 0) {
+            // no windows at all: counted by the rank whose candidate range holds this scaffold's place in the numbering
+            const bool mine = (first[s] >= c0 && first[s] < c1) || (first[s] == total && rank == world - 1) ||
+                              (total == 0 && rank == world - 1);
+            if (!mine) continue;
+            t.j0 = 0; t.ncand = 0; t.base0 = 0; t.own0 = 0; t.own1 = size;
+            tiles.push_back(t);
+        }
+    }
+    return tiles;
+}
+
+// one past the last scaffold position a tile keeps resident
+int64_t tile_end(const frisk_ctx::Batch::Tile& t, int32_t w, int32_t inc, int kmax) {
+    if (t.ncand == 0 || t.kind == 1) return t.size;
+    int64_t b = (t.j0 + t.ncand - 1) * inc + w;
+    if (b > t.size) b = t.size;
+    return std::max<int64_t>(b, std::min<int64_t>(t.size, t.own1 + kmax - 1));
+}
+
+// Native FASTA reader with the record semantics of the reference's iterFasta (L139-164).  Records are appended to `stage`
+// in the upload layout: sequence bytes, then one PAD byte.  Returns false with `err` set on failure.
+static bool parse_fasta(const char* path, std::vector<std::string>& names, std::vector<int64_t>& lens, std::vector<uint8_t>& stage,
+                        std::string& err) {
+    gzFile fh = gzopen(path, "rb");                         // reads plain files too
+    if (!fh) { err = std::string("cannot open FASTA file: ") + path; return false; }
+    gzbuffer(fh, 1 << 20);
+    // records are appended to `stage` in the upload layout: sequence bytes, then one PAD byte
+    std::string line, carry;
+    std::vector<char> buf(1 << 22);
+    bool in_record = false;
+    int64_t cur_len = 0;
+    auto is_space = [](unsigned char ch) { return ch == ' ' || (ch >= 9 && ch <= 13); };       // str.strip() on ASCII
+    auto finish_record = [&]() {
+        if (in_record) { lens.push_back(cur_len); stage.push_back(uint8_t(FRISK_PAD_BYTE)); }
+    };
+    auto handle_line = [&](const char* b, const char* e) {
+        while (b < e && is_space((unsigned char)*b)) ++b;
+        while (e > b && is_space((unsigned char)e[-1])) --e;
+        if (b == e) return;                                                 // blank line (L150-151)
+        if (*b == '>') {                                                    // header (L152-157)
+            const char* hb = b;
+            const char* he = e;
+            while (hb < he && *hb == '>') ++hb;                             // line.strip('>')
+            while (he > hb && he[-1] == '>') --he;
+            while (hb < he && is_space((unsigned char)*hb)) ++hb;           // .split()[0]
+            const char* te = hb;
+            while (te < he && !is_space((unsigned char)*te)) ++te;
+            if (te == hb) { if (err.empty()) err = "FASTA header without a name"; return; }    // IndexError in the reference
+            finish_record();
+            names.emplace_back(hb, te);
+            in_record = true;
+            cur_len = 0;
+        } else if (in_record) {                                             // sequence line (L158-160)
+            stage.insert(stage.end(), reinterpret_cast<const uint8_t*>(b), reinterpret_cast<const uint8_t*>(e));
+            cur_len += e - b;
+        }                                                                   // text before the first header is dropped (L157)
+    };
+    for (;;) {
+        const int got = gzread(fh, buf.data(), unsigned(buf.size()));
+        if (got < 0) { gzclose(fh); err = std::string("read error in FASTA file: ") + path; return false; }
+        if (got == 0) break;
+        const char* p = buf.data();
+        const char* end = p + got;
+        while (p < end) {
+            const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
+            if (!nl) { carry.append(p, end); break; }
+            if (!carry.empty()) { carry.append(p, nl); handle_line(carry.data(), carry.data() + carry.size()); carry.clear(); }
+            else handle_line(p, nl);
+            p = nl + 1;
+        }
+    }
+    gzclose(fh);
+    if (!carry.empty()) handle_line(carry.data(), carry.data() + carry.size());
+    finish_record();
+    if (!err.empty()) { err += std::string(": ") + path; return false; }
+    if (lens.size() > size_t(0x7FFFFFFF)) { err = "too many FASTA records"; return false; }
+    return true;
 }
 
 }  // namespace
@@ -401,63 +540,11 @@ int frisk_seq_load(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens
 
 int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t* total_len_out) {
     if (!c || !path) return FRISK_E_ARG;
-    gzFile fh = gzopen(path, "rb");                         // reads plain files too
-    if (!fh) return fail(c, FRISK_E_ARG, std::string("cannot open FASTA file: ") + path);
-    gzbuffer(fh, 1 << 20);
-    // records are appended to `stage` in the upload layout: sequence bytes, then one PAD byte
     std::vector<uint8_t> stage;
     std::vector<int64_t> lens;
     std::vector<std::string> names;
-    std::string line, carry;
-    std::vector<char> buf(1 << 22);
-    bool in_record = false;
-    int64_t cur_len = 0;
-    auto is_space = [](unsigned char ch) { return ch == ' ' || (ch >= 9 && ch <= 13); };       // str.strip() on ASCII
-    auto finish_record = [&]() {
-        if (in_record) { lens.push_back(cur_len); stage.push_back(uint8_t(FRISK_PAD_BYTE)); }
-    };
     std::string err;
-    auto handle_line = [&](const char* b, const char* e) {
-        while (b < e && is_space((unsigned char)*b)) ++b;
-        while (e > b && is_space((unsigned char)e[-1])) --e;
-        if (b == e) return;                                                 // blank line (L150-151)
-        if (*b == '>') {                                                    // header (L152-157)
-            const char* hb = b;
-            const char* he = e;
-            while (hb < he && *hb == '>') ++hb;                             // line.strip('>')
-            while (he > hb && he[-1] == '>') --he;
-            while (hb < he && is_space((unsigned char)*hb)) ++hb;           // .split()[0]
-            const char* te = hb;
-            while (te < he && !is_space((unsigned char)*te)) ++te;
-            if (te == hb) { if (err.empty()) err = "FASTA header without a name"; return; }    // IndexError in the reference
-            finish_record();
-            names.emplace_back(hb, te);
-            in_record = true;
-            cur_len = 0;
-        } else if (in_record) {                                             // sequence line (L158-160)
-            stage.insert(stage.end(), reinterpret_cast<const uint8_t*>(b), reinterpret_cast<const uint8_t*>(e));
-            cur_len += e - b;
-        }                                                                   // text before the first header is dropped (L157)
-    };
-    for (;;) {
-        const int got = gzread(fh, buf.data(), unsigned(buf.size()));
-        if (got < 0) { gzclose(fh); return fail(c, FRISK_E_ARG, std::string("read error in FASTA file: ") + path); }
-        if (got == 0) break;
-        const char* p = buf.data();
-        const char* end = p + got;
-        while (p < end) {
-            const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
-            if (!nl) { carry.append(p, end); break; }
-            if (!carry.empty()) { carry.append(p, nl); handle_line(carry.data(), carry.data() + carry.size()); carry.clear(); }
-            else handle_line(p, nl);
-            p = nl + 1;
-        }
-    }
-    gzclose(fh);
-    if (!carry.empty()) handle_line(carry.data(), carry.data() + carry.size());
-    finish_record();
-    if (!err.empty()) return fail(c, FRISK_E_ARG, err + ": " + path);
-    if (lens.size() > size_t(0x7FFFFFFF)) return fail(c, FRISK_E_ARG, "too many FASTA records");
+    if (!parse_fasta(path, names, lens, stage, err)) return fail(c, FRISK_E_ARG, err);
     HIPC(c, hipSetDevice(c->device));
     int rc = layout_batch(c, lens.data(), int32_t(lens.size()));
     if (rc) return rc;
@@ -477,12 +564,67 @@ int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t
     return FRISK_OK;
 }
 
-int32_t frisk_seq_count(const frisk_ctx* c) { return (c && c->b().have_seq) ? c->b().n_seq : 0; }
+int frisk_fasta_load_shard(frisk_ctx* c, const char* path, int32_t w, int32_t inc, uint32_t flags, int32_t rank, int32_t world,
+                           int32_t* n_seq_out, int64_t* total_len_out, int64_t* cand_begin, int64_t* cand_end) {
+    if (!c || !path) return FRISK_E_ARG;
+    if (w < 1 || inc < 1) return fail(c, FRISK_E_ARG, "window length and increment must be >= 1");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, FRISK_E_ARG, "rank outside [0, world)");
+    std::vector<uint8_t> stage;
+    std::vector<int64_t> lens;
+    std::vector<std::string> names;
+    std::string err;
+    if (!parse_fasta(path, names, lens, stage, err)) return fail(c, FRISK_E_ARG, err);
+    HIPC(c, hipSetDevice(c->device));
+    int64_t c0 = 0, c1 = 0;
+    std::vector<frisk_ctx::Batch::Tile> tiles = plan_tiles(lens, w, inc, (flags & FRISK_SCAN_SCAFFOLDS_ALL) != 0, c->kmax, rank, world, c0, c1);
+    std::vector<int64_t> rec_off(lens.size());          // where record s starts in `stage`
+    int64_t pos = 0;
+    for (size_t s = 0; s < lens.size(); ++s) { rec_off[s] = pos; pos += lens[s] + 1; }
+    std::vector<int64_t> tlen(tiles.size());
+    for (size_t t = 0; t < tiles.size(); ++t) tlen[t] = tile_end(tiles[t], w, inc, c->kmax) - tiles[t].base0;
+    int rc = layout_batch(c, tlen.data(), int32_t(tiles.size()));
+    if (rc) return rc;
+    frisk_ctx::Batch& B = c->b();
+    // the rank's tiles, gathered into one upload buffer in the batch layout
+    std::vector<uint8_t> up(size_t(B.padded_len), uint8_t(FRISK_PAD_BYTE));
+    for (size_t t = 0; t < tiles.size(); ++t)
+        if (tlen[t] > 0)
+            std::memcpy(up.data() + B.seq_off[t], stage.data() + rec_off[size_t(tiles[t].scaf)] + tiles[t].base0, size_t(tlen[t]));
+    HIPC(c, B.d_ascii.reserve(size_t(B.padded_len)));
+    HIPC(c, hipMemcpyAsync(B.d_ascii.p, up.data(), up.size(), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    rc = alloc_packed(c);
+    if (rc) return rc;
+    rc = run_pack(c);
+    if (rc) return rc;
+    B.tiled = true;
+    B.tiles = tiles;
+    B.tile_w = w; B.tile_inc = inc; B.tile_flags = flags & FRISK_SCAN_SCAFFOLDS_ALL;
+    B.cand_begin = c0; B.cand_end = c1;
+    B.g_name = names;
+    B.g_len = lens;
+    int64_t total = 0;
+    for (int64_t v : lens) total += v;
+    if (n_seq_out) *n_seq_out = int32_t(lens.size());
+    if (total_len_out) *total_len_out = total;
+    if (cand_begin) *cand_begin = c0;
+    if (cand_end) *cand_end = c1;
+    return FRISK_OK;
+}
+
+int32_t frisk_seq_count(const frisk_ctx* c) {
+    if (!c || !c->b().have_seq) return 0;
+    return c->b().tiled ? int32_t(c->b().g_len.size()) : c->b().n_seq;
+}
 const char* frisk_seq_name(const frisk_ctx* c, int32_t s) {
-    return (c && c->b().have_seq && s >= 0 && s < c->b().n_seq) ? c->b().seq_name[size_t(s)].c_str() : "";
+    if (!c || !c->b().have_seq || s < 0) return "";
+    if (c->b().tiled) return size_t(s) < c->b().g_name.size() ? c->b().g_name[size_t(s)].c_str() : "";
+    return s < c->b().n_seq ? c->b().seq_name[size_t(s)].c_str() : "";
 }
 int64_t frisk_seq_len(const frisk_ctx* c, int32_t s) {
-    return (c && c->b().have_seq && s >= 0 && s < c->b().n_seq) ? c->b().seq_len[size_t(s)] : -1;
+    if (!c || !c->b().have_seq || s < 0) return -1;
+    if (c->b().tiled) return size_t(s) < c->b().g_len.size() ? c->b().g_len[size_t(s)] : -1;
+    return s < c->b().n_seq ? c->b().seq_len[size_t(s)] : -1;
 }
 
 // ---- double-buffered residency: upload the NEXT batch while the resident one is being profiled / scanned ----------
@@ -585,6 +727,7 @@ int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t s
 int frisk_seq_read(frisk_ctx* c, int32_t s, int64_t offset, int64_t n, uint8_t* out) {
     if (!c || !out) return FRISK_E_ARG;
     if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
+    if (c->b().tiled) return fail(c, FRISK_E_STATE, "frisk_seq_read: the resident batch holds tiles, not whole scaffolds");
     if (s < 0 || s >= c->b().n_seq) return fail(c, FRISK_E_ARG, "sequence index out of range");
     if (offset < 0 || n < 0 || offset + n > c->b().seq_len[size_t(s)]) return fail(c, FRISK_E_ARG, "range outside the scaffold");
     if (n == 0) return FRISK_OK;
@@ -610,9 +753,28 @@ int frisk_profile_reset(frisk_ctx* c) {
     return FRISK_OK;
 }
 
+static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1);
+
 int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
     if (!c) return FRISK_E_ARG;
     if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "frisk_profile_add: no resident sequence batch");
+    if (c->b().tiled) {
+        // a tiled batch: "the whole batch" means the positions this rank OWNS (every base of the genome is owned by exactly
+        // one rank; the K-1 bases kept behind an owned range belong to the words that start inside it)
+        if (!(p0 < 0 && p1 < 0)) return fail(c, FRISK_E_ARG, "frisk_profile_add: a tiled batch is profiled as a whole (-1, -1)");
+        const frisk_ctx::Batch& B = c->b();
+        for (size_t t = 0; t < B.tiles.size(); ++t) {
+            const frisk_ctx::Batch::Tile& T = B.tiles[t];
+            if (T.own1 <= T.own0) continue;
+            int rc = profile_add_range(c, mask_host, B.seq_off[t] + (T.own0 - T.base0), B.seq_off[t] + (T.own1 - T.base0));
+            if (rc) return rc;
+        }
+        return FRISK_OK;
+    }
+    return profile_add_range(c, mask_host, p0, p1);
+}
+
+static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
     if (p0 < 0 && p1 < 0) { p0 = 0; p1 = c->b().padded_len; }
     if (p0 < 0 || p1 > c->b().padded_len || p0 > p1) return fail(c, FRISK_E_ARG, "position range outside the batch");
     HIPC(c, hipSetDevice(c->device));
@@ -725,21 +887,30 @@ int frisk_scan_plan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_
         return FRISK_OK;
     }
     HIPC(c, hipSetDevice(c->device));
-    c->h_desc.assign(size_t(c->b().n_seq) + 1, ScafDesc());
+    const frisk_ctx::Batch& B = c->b();
+    if (B.tiled && (w != B.tile_w || inc != B.tile_inc || (flags & FRISK_SCAN_SCAFFOLDS_ALL) != B.tile_flags))
+        return fail(c, FRISK_E_ARG, "the resident batch holds the tiles of another window geometry (frisk_fasta_load_shard)");
+    c->h_desc.assign(size_t(B.n_seq) + 1, ScafDesc());
     int64_t cand = 0, maxwin = 0;
-    for (int32_t s = 0; s < c->b().n_seq; ++s) {
+    for (int32_t s = 0; s < B.n_seq; ++s) {
         ScafDesc& d = c->h_desc[size_t(s)];
-        d.off = c->b().seq_off[size_t(s)];
-        d.size = c->b().seq_len[size_t(s)];
+        d.off = B.seq_off[size_t(s)];
         d.cand0 = cand;
-        plan_scaffold(d.size, w, inc, all, d.ncand, d.kind);
         d.pad_ = 0;
+        if (B.tiled) {              // candidates are numbered from the rank's first one; the windows were chosen at load time
+            const frisk_ctx::Batch::Tile& t = B.tiles[size_t(s)];
+            d.size = t.size; d.base0 = t.base0; d.j0 = t.j0; d.ncand = t.ncand; d.kind = t.kind;
+        } else {
+            d.size = B.seq_len[size_t(s)];
+            d.base0 = 0; d.j0 = 0;
+            plan_scaffold(d.size, w, inc, all, d.ncand, d.kind);
+        }
         if (d.ncand > 0) maxwin = std::max<int64_t>(maxwin, d.kind == 1 ? d.size : w);
         cand += d.ncand;
     }
-    ScafDesc& sentinel = c->h_desc[size_t(c->b().n_seq)];       // keeps the binary search in range
-    sentinel.off = c->b().padded_len; sentinel.size = 0; sentinel.cand0 = cand; sentinel.ncand = 0; sentinel.kind = 0;
-    sentinel.pad_ = 0;
+    ScafDesc& sentinel = c->h_desc[size_t(B.n_seq)];       // keeps the binary search in range
+    sentinel.off = B.padded_len; sentinel.size = 0; sentinel.cand0 = cand; sentinel.ncand = 0; sentinel.kind = 0;
+    sentinel.base0 = 0; sentinel.j0 = 0; sentinel.pad_ = 0;
     if (maxwin > 0x7FFFFFFF) return fail(c, FRISK_E_ARG, "a window longer than 2^31-1 bases");
     HIPC(c, c->d_desc.reserve(c->h_desc.size()));
     HIPC(c, hipMemcpyAsync(c->d_desc.p, c->h_desc.data(), c->h_desc.size() * sizeof(ScafDesc), hipMemcpyHostToDevice,
@@ -846,7 +1017,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     // width 0 = adaptive (the default), 4 / 8 = fixed, anything else = off (scan_kernel.h's 16-bit form for everything)
     int width = FRISK_K8_WIDTH;
     if (const char* ev = tune_env("FRISK_K8_BITS")) width = std::atoi(ev);
-    const bool narrow = k8 && c->kmin <= 5 && c->plan_maxwin <= 5120 && (width == 0 || width == 4 || width == 8) && !quart;
+    // (decided by -w alone: rescued small scaffolds beyond the kernel's reach are handed on per window, see scan8_kernel.h)
+    const bool narrow = k8 && c->kmin <= 5 && w <= 5120 && c->plan_maxwin <= 65535 && (width == 0 || width == 4 || width == 8) && !quart;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
     if (c->plan_maxwin > 65535) {
@@ -872,7 +1044,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         HIPC(c, c->d_ovf_list.reserve(N));
         HIPC(c, c->d_ovf_list2.reserve(N));
         HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 4 * sizeof(unsigned int), c->stream));
-        const bool small_w = c->plan_maxwin <= 2048;
+        const bool small_w = w <= 2048;
         int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), 8));
         if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk8 = std::max<int64_t>(1, std::atoll(ev));
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
@@ -907,9 +1079,11 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         P.in_list = c->d_ovf_list2.p; P.in_count = c->d_ovf_count.p + 1;
         grid = int(std::min<int64_t>(n, int64_t(c->num_cu)));
         if (grid >= 8) grid &= ~7;
-        if (debug) FRISK_LAUNCH(512, true, 16, true);
+        if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
         else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
-        else FRISK_LAUNCH(512, true, 10, false);
+        else if (its == 10) FRISK_LAUNCH(512, true, 10, false);
+        else if (its == 16) FRISK_LAUNCH(512, true, 16, false);
+        else FRISK_LAUNCH(1024, true, 0, false);
     } else if (k8 && !debug && quart) {
         // K = 8 with TWO independent 256-thread workgroups per CU: the order-8 table serves one leading base at a time
         // (32 KiB), the window's max-mers are bucketed by leading base and handled in four passes (scan_kernel.h, QUART)
@@ -987,6 +1161,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     HIPC(c, hipStreamSynchronize(c->stream));
     c->scan_stat[1] = novf[0];
     c->scan_stat[2] = novf[1];
+    if (c->b().tiled)               // descriptor index -> index of the scaffold in the FASTA
+        for (size_t r = 0; r < N; ++r) seq_index[r] = c->b().tiles[size_t(seq_index[r])].scaf;
     float ms = 0;
     HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->ms[0] = ms;
@@ -1027,6 +1203,17 @@ int frisk_scan_ivom(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_
     }
     return FRISK_OK;
 }
+
+char* frisk_format_rows(int64_t n, const char* const* names, const int32_t* seq_index, const int64_t* start, const int64_t* stop,
+                        const uint8_t* kld_is_int0, const double* kld, const double* gc, const double* pi, const double* si,
+                        const double* cri, int64_t* out_len) {
+    if (out_len) *out_len = 0;
+    if (n < 0 || (n > 0 && (!names || !seq_index || !start || !stop || !kld || !gc))) return nullptr;
+    if ((pi || si || cri) && !(pi && si && cri)) return nullptr;
+    frisk_text::Columns c{n, names, seq_index, start, stop, kld_is_int0, kld, gc, pi, si, cri};
+    return frisk_text::format_all(c, out_len);
+}
+void frisk_free(void* p) { std::free(p); }
 
 int64_t frisk_last_scan_stat(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 3) ? c->scan_stat[which] : -1; }
 

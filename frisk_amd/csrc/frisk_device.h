@@ -18,10 +18,12 @@
 #define FRISK_PAD_BYTE 0
 
 struct ScafDesc {
-    int64_t off;     // padded position of the scaffold's first base
-    int64_t size;    // scaffold length in bases
-    int64_t cand0;   // index of the scaffold's first candidate window
-    int64_t ncand;   // number of candidate windows (0: scaffold skipped)
+    int64_t off;     // padded position of the first RESIDENT base of the scaffold
+    int64_t size;    // scaffold length in bases (the whole scaffold, also when only a tile of it is resident)
+    int64_t cand0;   // index of the first candidate window described here
+    int64_t ncand;   // number of candidate windows (0: none on this device)
+    int64_t base0;   // position inside the scaffold of that first resident base (0 unless the batch holds a tile)
+    int64_t j0;      // window index inside the scaffold of candidate cand0 (0 unless the batch holds a tile)
     int32_t kind;    // 0 = regular windows (L226-246), 1 = whole scaffold as one window (L211-221)
     int32_t pad_;
 };

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     const int64_t nchunks = listed || P.sel_mode == 0 ? nall : (P.sel_mode == 1 ? nsample : nall - nsample);
 
     ScafDesc d;
-    d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
+    d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0; d.base0 = 0; d.j0 = 0;
     int dsi = -1;
     uint32_t parity = 0;
 
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             int tid = tid0, kmin = kmin0;
             asm volatile("" : "+v"(tid), "+s"(kmin));
             const int lane = tid & 63;
-            const int64_t j = cand - d.cand0;
+            const int64_t j = cand - d.cand0 + d.j0;           // window index inside the scaffold
             int64_t st, rep_start, rep_stop;
             int n;
             bool jump = false;
@@ -182,8 +182,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     n = int(d.size - st);
                 }
             }
-            const int64_t g0 = d.off + st;
+            const int64_t g0 = d.off + (st - d.base0);            // resident position of the window's first base
             const int64_t row = cand - P.c0;
+            if (n > NT * ITS) {
+                // a rescued small scaffold (--scaffoldsAll, L211-221: up to 1.75 w bases) longer than this kernel's lanes cover:
+                // straight to the wider forms - per WINDOW, so that which kernel scores a window never depends on what else
+                // is resident (a rank of a multi-GPU job sees other scaffolds than the one-GPU run)
+                if (tid == 0) { const unsigned int slot = atomicAdd(P.out_count, 1u); P.out_list[slot] = cand; }
+                continue;
+            }
             uint32_t* misc = misc_base + parity * FRISK8_SLOTS;
             uint32_t* misc_other = misc_base + (parity ^ 1u) * FRISK8_SLOTS;
             parity ^= 1u;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(FRISK_BIG_NT) void scan_big_kernel(const ScanParams
     const int64_t offK = table_offset(kmin, kmax);
     const uint32_t nK = 1u << (2 * kmax);
     ScafDesc d;
-    d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
+    d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0; d.base0 = 0; d.j0 = 0;
     int dsi = -1;
     for (int64_t cand = P.c0 + blockIdx.x; cand < P.c1; cand += gridDim.x) {
         // ---- which scaffold / window is this candidate? (as in scan_kernel)
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(FRISK_BIG_NT) void scan_big_kernel(const ScanParams
             d = P.descs[lo];
             dsi = lo;
         }
-        const int64_t j = cand - d.cand0;
+        const int64_t j = cand - d.cand0 + d.j0;           // window index inside the scaffold
         int64_t st, rep_start, rep_stop, n;
         bool jump = false;
         if (d.kind == 1) { st = 0; n = d.size; rep_start = 1; rep_stop = d.size; }              // L219
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(FRISK_BIG_NT) void scan_big_kernel(const ScanParams
                 n = d.size - st;
             }
         }
-        const int64_t g0 = d.off + st;
+        const int64_t g0 = d.off + (st - d.base0);            // resident position of the window's first base
         const int64_t row = cand - P.c0;
         if (tid < 8) tl[tid] = 0;
         __syncthreads();

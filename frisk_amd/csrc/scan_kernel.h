@@ -438,7 +438,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     const int64_t nchunks = (ncand + chunk - 1) / chunk;
 
     ScafDesc d;
-    d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0;
+    d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0; d.base0 = 0; d.j0 = 0;
     int dsi = -1;
     uint32_t parity = 0;
 #ifdef FRISK_STAMPS
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
 #ifdef FRISK_STAMPS
             ++stamp_win;
 #endif
-            const int64_t j = cand - d.cand0;
+            const int64_t j = cand - d.cand0 + d.j0;           // window index inside the scaffold
             int64_t st;                // 0-based first base of the window inside the scaffold
             int64_t rep_start, rep_stop;   // coordinates as the reference reports them
             int n;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     n = int(d.size - st);
                 }
             }
-            const int64_t g0 = d.off + st;
+            const int64_t g0 = d.off + (st - d.base0);            // resident position of the window's first base
             const int64_t row = cand - P.c0;
             STAMP(0)
             uint32_t* misc = misc_base + parity * FRISK_MISC_SLOTS;         // this window's counters

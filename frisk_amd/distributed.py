@@ -132,27 +132,116 @@ def _gather_rows(dist, group, rank, world, res, seq_global, cand_key, qnames, ri
     return rows
 
 
-def run_sharded_files(engine, host_path, w, inc, mask_host=False, rip=False, scaffolds_all=False, group=None,
-                      query_path=None):
-    """The same job straight from FASTA files: REPLICATED data, sharded work.  Every rank reads the whole file with
-    the native reader (`Engine.load_fasta`; a 3 Gb assembly is < 1.3 GB packed, nothing beside 288 GB of HBM), counts
-    the k-mers that start in its contiguous range of padded positions, joins the one all-reduce, and scans its
-    contiguous range of candidate windows - balanced whatever the scaffold lengths, and no sequence ever exists as
-    a Python string.  Rows as `run_sharded`."""
+# ---- window-tile sharding with halo: the host-side specification of frisk_fasta_load_shard ----------------
+def plan_scaffold(size, w, inc, scaffolds_all):
+    """(number of candidate windows, kind) of one scaffold - crawlGenome L194-251: kind 1 = the whole scaffold as one window
+    (small scaffold, only with --scaffoldsAll), kind 0 = floor(size / inc) regular windows."""
+    if float(size) <= float(w) + ((float(w) * 0.75) - float(inc)):
+        return (1 if scaffolds_all else 0), 1
+    return (len(range(0, size - inc + 1, inc)) if size - inc + 1 > 0 else 0), 0
+
+
+def plan_tiles(lens, w, inc, scaffolds_all, kmax, rank, world):
+    """What rank `rank` of `world` keeps resident.  Returns ((cand_begin, cand_end), tiles); a tile is a dict
+    scaf / size / base0 (first resident base) / end (one past the last) / j0, ncand (its windows inside the scaffold) /
+    kind / own0, own1 (the positions whose k-mers this rank counts).  Properties (tested): the candidate ranges of the ranks
+    partition the job's numbering, every window's bases are resident on its rank, the owned ranges partition every
+    scaffold, and K-1 bases behind every owned range are resident."""
+    plans = [plan_scaffold(n, w, inc, scaffolds_all) for n in lens]
+    first, total = [], 0
+    for nc, _ in plans:
+        first.append(total)
+        total += nc
+    c0, c1 = split_range(total, rank, world)
+    tiles = []
+    for s, size in enumerate(lens):
+        nc, kind = plans[s]
+        ja, jb = max(c0, first[s]) - first[s], min(c1, first[s] + nc) - first[s]
+        if jb > ja:
+            t = dict(scaf=s, size=size, kind=kind, j0=ja, ncand=jb - ja)
+            if kind == 1:
+                t.update(base0=0, own0=0, own1=size, end=size)
+            else:
+                a, b = ja * inc, (jb - 1) * inc + w
+                if b > size:                                    # the range includes jumpback windows (L230-243)
+                    b, a = size, min(a, max(0, size - w))
+                own1 = size if jb == nc else jb * inc
+                t.update(base0=a, own0=ja * inc, own1=own1, end=max(b, min(size, own1 + kmax - 1)))
+            tiles.append(t)
+        elif nc == 0:
+            mine = (c0 <= first[s] < c1) or (first[s] == total and rank == world - 1) or (total == 0 and rank == world - 1)
+            if mine:
+                tiles.append(dict(scaf=s, size=size, kind=kind, j0=0, ncand=0, base0=0, own0=0, own1=size, end=size))
+    return (c0, c1), tiles
+
+
+def _gather_table(dist, group, rank, world, res, names, rip):
+    """The rows of all ranks on rank 0 as one ScoreTable in the reference's output order.  Ranks hold consecutive candidate
+    ranges, so rank order IS output order.  Returns (table, zero_weight) on rank 0 and (None, zero_weight) elsewhere, where
+    zero_weight tells every rank whether the reference would have died with ZeroDivisionError (L437)."""
+    from . import _ffi
+    from .table import ScoreTable
+    keep = res.kept
+    local = {"seq": res.seq_index[keep], "start": res.start[keep], "stop": res.stop[keep], "status": res.status[keep],
+             "kld": res.kld[keep], "gc": res.gc[keep]}
+    if rip:
+        local.update(pi=res.pi[keep], si=res.si[keep], cri=res.cri[keep])
+    if world > 1:
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(local, parts, dst=0, group=group)
+    else:
+        parts = [local]
+    table, flag = None, [False]
+    if rank == 0:
+        m = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        bad = np.nonzero((m["status"] & _ffi.ROW_ZERO_WEIGHT) != 0)[0]
+        n = int(bad[0]) if bad.size else len(m["seq"])            # the reference has written every row before the failing one
+        flag = [bool(bad.size)]
+        int0 = ((m["status"][:n] & _ffi.ROW_NO_MAXMER) != 0).astype(np.uint8)
+        table = ScoreTable(names, m["seq"][:n], m["start"][:n], m["stop"][:n], m["kld"][:n], m["gc"][:n],
+                           m["pi"][:n] if rip else None, m["si"][:n] if rip else None, m["cri"][:n] if rip else None, int0)
+    if world > 1:
+        dist.broadcast_object_list(flag, src=0, group=group)
+    return table, bool(flag[0])
+
+
+def profile_sharded(engine, host_path, w, inc, mask_host=False, scaffolds_all=False, group=None):
+    """Phase A of one job on this rank (computeKmers genomeMode, L1442): keep the rank's tiles of the host FASTA resident,
+    count the k-mers that start in the positions it owns, join the ONE all-reduce, finalise.  Every rank ends with the whole
+    genome's profile.  Returns the names of the FASTA's records."""
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    names = engine.load_fasta(host_path)
+    names, _ = engine.load_fasta_shard(host_path, w, inc, rank, world, scaffolds_all)
     engine.profile_reset()
-    p0, p1 = split_range(engine.padded_len, rank, world)
-    engine.profile_add(mask_host=mask_host, pos_begin=p0, pos_end=p1)
+    engine.profile_add(mask_host=mask_host)
     engine.profile_allreduce(group)
     engine.profile_finalize()
-    qnames = names
-    if query_path is not None and query_path != host_path:
-        qnames = engine.load_fasta(query_path)
-    total = engine.scan_plan(w, inc, scaffolds_all)
-    c0, c1 = split_range(total, rank, world)
-    res = engine.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all, c0=c0, c1=c1)
-    return _gather_rows(dist, group, rank, world, res, res.seq_index.astype(np.int64),
-                        np.arange(c0, c1, dtype=np.int64), qnames, rip)
+    return names
+
+
+def scan_sharded(engine, query_path, w, inc, rip=False, scaffolds_all=False, group=None, resident_names=None):
+    """Phase B (loop L1478-1494): scan the rank's candidate range of the query FASTA (its tiles are loaded here unless
+    `resident_names` says the query's tiles are resident already), gather on rank 0.  Returns (ScoreTable | None, zero_weight)."""
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    names = resident_names
+    if names is None:
+        names, _ = engine.load_fasta_shard(query_path, w, inc, rank, world, scaffolds_all)
+    res = engine.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
+    return _gather_table(dist, group, rank, world, res, names, rip)
+
+
+def run_sharded_files(engine, host_path, w, inc, mask_host=False, rip=False, scaffolds_all=False, group=None,
+                      query_path=None):
+    """One whole job straight from FASTA files, N ranks: window-tile sharding with halo - every rank parses the file with the
+    native reader but keeps resident (and uploads) only the bases of ITS candidate windows and of the positions it counts;
+    one all-reduce; rows gathered on rank 0.  Rows as `run_sharded` (rank 0; None elsewhere)."""
+    names = profile_sharded(engine, host_path, w, inc, mask_host, scaffolds_all, group)
+    same = query_path is None or query_path == host_path
+    table, _zero = scan_sharded(engine, query_path or host_path, w, inc, rip, scaffolds_all, group,
+                                resident_names=names if same else None)
+    if table is None:
+        return None
+    return [r[:3] + (1,) + r[3:] for r in table.rows()]         # (name, start, stop, status, kld, gc[, pi, si, cri])

@@ -171,6 +171,19 @@ class Engine:
         self.seq_lens = [int(self._lib.frisk_seq_len(self._ctx, i)) for i in range(self.n_seq)]
         return [self._lib.frisk_seq_name(self._ctx, i).decode("ascii", "replace") for i in range(self.n_seq)]
 
+    def load_fasta_shard(self, path, w, inc, rank, world, scaffolds_all=False):
+        """One rank's share of a multi-GPU job (window tiles + halo): parse the file natively, keep resident only the bases
+        of the rank's candidate windows and of the positions it counts.  Returns (names of ALL records, (cand_begin, cand_end)):
+        scan() on this batch numbers candidates from 0 = cand_begin."""
+        n, total, c0, c1 = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        flags = _ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0
+        self._check(self._lib.frisk_fasta_load_shard(self._ctx, os.fsencode(path), int(w), int(inc), flags, int(rank), int(world),
+                                                     C.byref(n), C.byref(total), C.byref(c0), C.byref(c1)))
+        self.n_seq = int(n.value)
+        self.seq_lens = [int(self._lib.frisk_seq_len(self._ctx, i)) for i in range(self.n_seq)]
+        names = [self._lib.frisk_seq_name(self._ctx, i).decode("ascii", "replace") for i in range(self.n_seq)]
+        return names, (int(c0.value), int(c1.value))
+
     def synth(self, lens, seed, island_frac=0.02, n_frac=0.0, lower_frac=0.0):
         lens = [int(x) for x in lens]
         arr = (C.c_int64 * max(len(lens), 1))(*lens)

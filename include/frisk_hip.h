@@ -88,6 +88,14 @@ int frisk_seq_set_names(frisk_ctx* ctx, const char* const* names, int32_t n_seq)
  * surrounding whitespace, blank lines skipped, case preserved) straight into the upload layout, and make its records
  * the resident batch.  Record names / lengths are then available from frisk_seq_name / frisk_seq_len. */
 int frisk_fasta_load(frisk_ctx* ctx, const char* path, int32_t* n_seq, int64_t* total_len);
+/* Multi-GPU form of frisk_fasta_load (window-tile sharding with halo): every rank parses the file, but keeps
+ * resident only what it needs for ITS share of the job - the candidate windows [*cand_begin, *cand_end) of the job's
+ * numbering (an equal contiguous share) and the positions whose k-mers it counts in phase A (every base of the genome
+ * belongs to exactly one rank; K-1 bases of halo behind each owned range).  The window geometry is fixed here; frisk_scan
+ * on the batch then numbers candidates from 0 = *cand_begin, frisk_profile_add(-1,-1) counts the owned positions, and
+ * seq_index / frisk_seq_name / frisk_seq_len / frisk_seq_count refer to the records of the FASTA, as on one GPU. */
+int frisk_fasta_load_shard(frisk_ctx* ctx, const char* path, int32_t w, int32_t inc, uint32_t flags, int32_t rank,
+                           int32_t world, int32_t* n_seq, int64_t* total_len, int64_t* cand_begin, int64_t* cand_end);
 int32_t frisk_seq_count(const frisk_ctx* ctx);
 const char* frisk_seq_name(const frisk_ctx* ctx, int32_t seq_index);   /* "" for batches not loaded from FASTA */
 int64_t frisk_seq_len(const frisk_ctx* ctx, int32_t seq_index);
@@ -152,6 +160,16 @@ int frisk_scan_ivom(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int6
  * which = 0: counter width of the bulk launch (4 or 8; 16 = the narrow kernel was not used),
  *         1: windows handed from 4-bit to 8-bit counters,   2: windows handed on to 16-bit counters. */
 int64_t frisk_last_scan_stat(const frisk_ctx* ctx, int which);
+
+/* The rows of the score table as text, exactly as the reference's scan loop writes them (L1487-1494): tab-separated
+ * name, start, stop, windowKLD, GC[, PI, SI, CRI], one line per row, every value as Python 2's str() prints it (floats:
+ * 12 significant digits, '.0' on integral values, nan / inf).  Host-side, multi-threaded; replaces a per-row Python loop
+ * that costs tens of seconds at 3 M rows.  names: one per scaffold; kld_is_int0 (nullable): rows whose KLD is the int 0
+ * (L465: no max-mer); pi/si/cri: all three or none.  Returns a malloc'd, NUL-terminated buffer (frisk_free) and its length. */
+char* frisk_format_rows(int64_t n_rows, const char* const* names, const int32_t* seq_index, const int64_t* start,
+                        const int64_t* stop, const uint8_t* kld_is_int0, const double* kld, const double* gc,
+                        const double* pi, const double* si, const double* cri, int64_t* out_len);
+void frisk_free(void* ptr);
 
 /* Page-locked host memory for result buffers: D2H copies into it are asynchronous and run at PCIe rate
  * (pageable buffers work too, at a fraction of it).  Free with frisk_host_free before frisk_destroy. */

@@ -17,6 +17,7 @@ class FakeEngine:
         self.profile = None
 
     def load(self, seqs):
+        self.tiles = None
         self.seqs = [N.Encoded(s) for s in seqs]
         self.off, pos = [], 0
         for e in self.seqs:
@@ -30,6 +31,16 @@ class FakeEngine:
         self.load(seqs)
         return names
 
+    def load_fasta_shard(self, path, w, inc, rank, world, scaffolds_all=False):
+        """The tiles of one rank (frisk_amd.distributed.plan_tiles is the specification of frisk_fasta_load_shard)."""
+        from frisk_amd.distributed import plan_tiles
+        from frisk_amd.fasta import readFasta
+        names, seqs = readFasta(path)
+        (c0, c1), tiles = plan_tiles([len(s) for s in seqs], w, inc, scaffolds_all, self.kmax, rank, world)
+        self.load([seqs[t["scaf"]][t["base0"]:t["end"]] for t in tiles])
+        self.tiles, self.tile_geom = tiles, (w, inc, scaffolds_all)
+        return names, (c0, c1)
+
     @property
     def padded_len(self):
         return self._padded
@@ -39,6 +50,11 @@ class FakeEngine:
         self.profile = None
 
     def profile_add(self, mask_host=False, pos_begin=-1, pos_end=-1):
+        if self.tiles is not None:                       # a tiled batch: the positions this rank owns
+            assert pos_begin < 0 and pos_end < 0
+            ranges = [(t["own0"] - t["base0"], t["own1"] - t["base0"]) for t in self.tiles]
+            self.raw += N.raw_profile(self.seqs, self.kmin, self.kmax, mask_host, ranges)
+            return
         if pos_begin < 0 and pos_end < 0:
             pos_begin, pos_end = 0, self._padded
         ranges = [(pos_begin - o, pos_end - o) for o in self.off]
@@ -64,6 +80,13 @@ class FakeEngine:
 
     def _candidates(self, w, inc, scaffolds_all):
         out = []
+        if self.tiles is not None:
+            assert (w, inc, scaffolds_all) == self.tile_geom
+            for ti, t in enumerate(self.tiles):          # the tile's windows, in the scaffold's own coordinates
+                wins = list(N.iter_windows(t["size"], w, inc, scaffolds_all))[t["j0"]:t["j0"] + t["ncand"]]
+                for a, b, start, stop in wins:
+                    out.append((ti, a - t["base0"], b - t["base0"], start, stop))
+            return out
         for si, e in enumerate(self.seqs):
             for a, b, start, stop in N.iter_windows(e.n, w, inc, scaffolds_all):
                 out.append((si, a, b, start, stop))
@@ -86,7 +109,7 @@ class FakeEngine:
                        cri=np.full(n, nan) if rip else None, counts=None, meta=None)
         for t, (si, a, b, start, stop) in enumerate(cands[c0:c1]):
             win = self.seqs[si].slice(a, b)
-            r.seq_index[t], r.start[t], r.stop[t] = si, start, stop
+            r.seq_index[t], r.start[t], r.stop[t] = (self.tiles[si]["scaf"] if self.tiles is not None else si), start, stop
             if (win.n - int(win.upper.sum())) >= 0.3 * win.n:
                 continue
             row = N.score_window(win, ig, self.kmin, self.kmax, rip)

@@ -76,3 +76,42 @@ def test_lpt_and_ranges():
     assert choose_mode(lens, 2) == "scaffold" and choose_mode([248956422], 8) == "range"
     parts = [split_range(1001, r, 8) for r in range(8)]
     assert parts[0][0] == 0 and parts[-1][1] == 1001 and all(parts[i][1] == parts[i + 1][0] for i in range(7))
+
+
+def test_tile_plan_properties():
+    """plan_tiles (the specification of frisk_fasta_load_shard): candidate ranges partition the job's numbering, every
+    window's bases are resident on its rank, owned ranges partition every scaffold, K-1 bases of halo follow each."""
+    from frisk_amd.distributed import plan_scaffold, plan_tiles
+    from oracle import frisk_oracle_np as N
+    rng = np.random.default_rng(12)
+    for trial in range(60):
+        w = int(rng.choice([400, 2000, 5000]))
+        inc = int(rng.choice([w // 10, w // 5, w // 2, w, w + w // 4, 3 * w]))
+        all_ = bool(rng.integers(0, 2))
+        lens = [int(x) for x in rng.choice([0, 7, w // 2, w, w + 1, 2 * w - 1, 3 * w + 17, 10 * w + 3, 57 * w], size=int(rng.integers(1, 9)))]
+        world = int(rng.choice([1, 2, 3, 5, 8]))
+        kmax = 8
+        total = sum(plan_scaffold(n, w, inc, all_)[0] for n in lens)
+        owned = [np.zeros(n, np.int32) for n in lens]
+        covered = []
+        prev_end = 0
+        for rank in range(world):
+            (c0, c1), tiles = plan_tiles(lens, w, inc, all_, kmax, rank, world)
+            assert c0 == prev_end and c1 >= c0
+            prev_end = c1
+            nloc = 0
+            for t in tiles:
+                s, size = t["scaf"], t["size"]
+                assert size == lens[s] and 0 <= t["base0"] <= t["own0"] <= t["own1"] <= t["end"] <= size
+                owned[s][t["own0"]:t["own1"]] += 1
+                assert t["end"] >= min(size, t["own1"] + kmax - 1)
+                wins = list(N.iter_windows(size, w, inc, all_))[t["j0"]:t["j0"] + t["ncand"]]
+                assert len(wins) == t["ncand"]
+                for a, b, _, _ in wins:
+                    assert t["base0"] <= a and b <= t["end"]
+                nloc += t["ncand"]
+            assert nloc == c1 - c0
+            covered.append(nloc)
+        assert prev_end == total and sum(covered) == total
+        for o in owned:
+            assert np.all(o == 1)

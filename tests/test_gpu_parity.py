@@ -538,3 +538,50 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
     for col in ("pi", "si", "cri"):
         assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
     assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
+
+
+@pytest.mark.parametrize("w,inc,scaffolds_all,kmin,kmax", [(5000, 1000, False, 1, 8), (2000, 2500, True, 1, 8), (3000, 700, True, 2, 6),
+                                                          (5000, 1000, True, 1, 8)])
+def test_window_tile_sharding_equals_one_gpu(tmp_path, w, inc, scaffolds_all, kmin, kmax):
+    """frisk_fasta_load_shard (window tiles + halo): the ranks of a 2-, 3- and 7-GPU job are played one after
+    the other on this GPU.  The sum of their raw profiles must be the one-GPU profile bit for bit (every base owned once),
+    and their rows, concatenated in rank order, must be the one-GPU rows bit for bit - with only the tiles resident."""
+    from frisk_amd import synth
+    lens = [333_337, 40_000, 7_001, 5_000, 0, 1_234, 120_500, 9_999, 64_000]
+    seqs = synth_seqs(lens, 41, island_frac=0.1, n_frac=0.08, lower_frac=0.05)
+    fa = tmp_path / "g.fa"
+    with open(fa, "wb") as fh:
+        for i, s in enumerate(seqs):
+            fh.write(b">s%d some description\n" % i)
+            for o in range(0, len(s), 70):
+                fh.write(s[o:o + 70] + b"\n")
+    rip = kmin <= 2
+    with make_engine(kmin, kmax) as e:
+        names = e.load_fasta(str(fa))
+        e.profile_reset(); e.profile_add(); whole_raw = e.profile_raw(); e.profile_finalize()
+        full = e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
+        whole_bases = e.padded_len
+        for world in (2, 3, 7):
+            raws, parts, ranges, resident = [], [], [], []
+            for rank in range(world):
+                nm, (c0, c1) = e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all)
+                assert nm == names and e.seq_lens == lens
+                resident.append(e.padded_len)
+                e.profile_reset(); e.profile_add()
+                raws.append(e.profile_raw())
+                ranges.append((c0, c1))
+            assert np.array_equal(np.sum(raws, axis=0), whole_raw)
+            assert ranges[0][0] == 0 and ranges[-1][1] == full.n_candidates
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            assert max(resident) < 0.75 * whole_bases                  # a rank holds its share, not the genome
+            for rank in range(world):
+                e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all)
+                e.profile_set_raw(whole_raw); e.profile_finalize()     # what the all-reduce leaves on every rank
+                r = e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
+                assert len(r) == ranges[rank][1] - ranges[rank][0]
+                parts.append(r)
+            for f in ("seq_index", "start", "stop", "status", "kld", "gc") + (("pi", "si", "cri") if rip else ()):
+                cat = np.concatenate([getattr(p, f) for p in parts])
+                assert np.array_equal(cat, getattr(full, f), equal_nan=True), (world, f)
+        with pytest.raises(Exception):
+            e.scan(w + 1, inc)                                          # the tiles were cut for another geometry
