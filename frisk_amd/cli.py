@@ -118,17 +118,39 @@ def _fmt():
     return pp.py3_str if os.environ.get("FRISK_FLOAT_REPR", "py2") == "py3" else pp.py2_str
 
 
-def write_table(path, columns, rows, echo=True):
+def write_table(path, table, echo=True):
     """Score table exactly as L1475-1494 lays it out: header, one tab-separated row per window, each row also
-    printed.  Floats as Python 2's str() prints them (12 significant digits) unless FRISK_FLOAT_REPR=py3."""
-    fmt = _fmt()
+    printed.  Floats as Python 2's str() prints them (12 significant digits) unless FRISK_FLOAT_REPR=py3.
+    The text comes from the library's native formatter in one piece (ScoreTable.text): no per-row Python."""
+    fmt = None if _fmt() is pp.py2_str else _fmt()
+    body = table.text(fmt)
     with open(path, "w") as fh:
-        fh.write("\t".join(columns) + "\n")
-        for r in rows:
-            line = "\t".join(fmt(v) for v in r)
-            fh.write(line + "\n")
-            if echo:
-                print(line)
+        fh.write("\t".join(table.columns) + "\n")
+        fh.write(body)
+    if echo:
+        sys.stdout.write(body)
+
+
+def _load_window_cache(path, rip):
+    """The window cache the reference pickles is the allWindows DataFrame (L1501); older builds of this package wrote
+    {columns, rows}.  Both are read."""
+    from .table import ScoreTable
+    with open(path, "rb") as fh:
+        cached = pickle.load(fh)
+    if hasattr(cached, "columns") and hasattr(cached, "itertuples"):
+        return ScoreTable.from_frame(cached, rip)
+    return ScoreTable.from_rows([tuple(r) for r in cached["rows"]], rip=rip)
+
+
+def _dump_window_cache(path, table):
+    """As the reference: pickle.dump(allWindows DataFrame) (L1501) - so that a reference run, or any tool that reads
+    *_KLD_window_*.p, can load it.  Without pandas: the {columns, rows} form."""
+    try:
+        obj = table.to_frame()
+    except ImportError:
+        obj = {"columns": table.columns, "rows": table.rows()}
+    with open(path, "wb") as fh:
+        pickle.dump(obj, fh, protocol=2)
 
 
 def main(argv=None):
@@ -142,9 +164,33 @@ def main(argv=None):
             dist.destroy_process_group()
 
 
+class _Clock:
+    """Wall-clock split of one run (logged at the end; FRISK_TIMING=1 also prints it as one JSON line on stderr)."""
+
+    def __init__(self):
+        import time
+        self._now = time.perf_counter
+        self.t0 = self._now()
+        self.last = self.t0
+        self.parts = []
+
+    def lap(self, label):
+        now = self._now()
+        self.parts.append((label, now - self.last))
+        self.last = now
+
+    def report(self):
+        total = self._now() - self.t0
+        log.info("timing: " + ", ".join("%s %.3f s" % p for p in self.parts) + ", total %.3f s" % total)
+        if os.environ.get("FRISK_TIMING") == "1":
+            import json
+            sys.stderr.write(json.dumps({"frisk_timing": dict(self.parts), "total_s": total}) + "\n")
+
+
 def _main(argv=None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(funcName)s - %(message)s")
     args = mainArgs(argv)
+    clock = _Clock()
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the sharded code path can be forced in a one-rank job (tests rehearse it on a single GPU)
@@ -165,78 +211,100 @@ def _main(argv=None):
     querySeq = args.querySeq or args.hostSeq
     if rank == 0 and not os.path.isdir(os.path.abspath(args.tempDir)):
         os.makedirs(os.path.abspath(args.tempDir))
+    if sharded:
+        dist.barrier()      # tempDir exists, and every rank sees the same cache files, before anyone looks for them
     for opt, why in (("cluster", "sklearn clustering is out of scope"),
                      ("graphics", "plotting is out of scope"), ("gffIn", "bedtools intersections are out of scope")):
         if getattr(args, opt):
             log.warning("--%s is not available in this build: %s", opt, why)
 
-    from .hotpath import HotPath, mapsToProfile
+    from .hotpath import HotPath
+    from . import distributed as D
     columns = _columns(args)
     rip = len(columns) == 8
+    w, inc, all_ = args.windowlen, args.increment, bool(args.scaffoldsAll)
     hp = HotPath(args.minWordSize, args.maxWordSize, device=local_rank)
+    table = None
     try:
-        # ---- phase A: host k-mer profile (L1436-1447); --recalc is store_false: giving it forces recomputation
-        if os.path.isfile(genomepickle) and args.recalc and not sharded:
+        # ---- phase A: host k-mer profile (L1436-1447); --recalc is store_false: giving it forces recomputation.
+        # Under torchrun every rank takes the same branch (the cache is a file all ranks see); rank 0 writes it.
+        resident_names = None       # sharded: names of the FASTA whose tiles are resident
+        if os.path.isfile(genomepickle) and args.recalc:
             log.info("Importing previously calculated genome kmers from %s", genomepickle)
             with open(genomepickle, "rb") as fh:
                 genomeKmers = pickle.load(fh, encoding="latin1")
             hp.setGenomeProfile(genomeKmers)
+            clock.lap("profile cache")
         else:
             log.info("Calculating kmers for host sequence: %s", args.hostSeq)
             if sharded:
-                rows_all = _sharded(hp, args, querySeq, rip)
+                resident_names = D.profile_sharded(hp.engine, args.hostSeq, w, inc, mask_host=args.maskHost, scaffolds_all=all_)
+                genomeKmers = hp.profileMaps() if rank == 0 else None
             else:
                 genomeKmers = hp.genomeProfile(args)
+            clock.lap("phase A (parse + upload + profile)")
+            if rank == 0:
                 with open(genomepickle, "wb") as fh:
                     pickle.dump(genomeKmers, fh, protocol=2)
-            if args.exitAfter == "GenomeKmers":
+                clock.lap("profile pickle")
+            if args.exitAfter == "GenomeKmers":                          # L1443-1445: before any window is scored
                 log.info("Finished counting kmers. Exiting.")
                 return 0
         # ---- phase B: window scores (L1454-1507)
-        if not sharded and os.path.isfile(windowsPickle) and args.recalcWin:
+        if os.path.isfile(windowsPickle) and args.recalcWin:
             log.info("Importing previously calculated window KLD scores from: %s", windowsPickle)
-            with open(windowsPickle, "rb") as fh:
-                cached = pickle.load(fh)
-            if hasattr(cached, "columns") and hasattr(cached, "itertuples"):       # a DataFrame, as the reference pickles
-                if "windowKLD" not in cached.columns:                               # legacy column name (L1458-1459)
-                    cached["windowKLD"] = cached["windowKLI"]
-                rows = [tuple(r) for r in cached[columns].itertuples(index=False, name=None)]
-            else:
-                rows = [tuple(r) for r in cached["rows"]]
-        else:
-            if sharded:
-                rows = rows_all
-            else:
-                rows, _ = hp.scanGenome(args, querySeq)
             if rank == 0:
-                write_table(os.path.join(args.tempDir, args.outfile), columns, rows)
-                with open(windowsPickle, "wb") as fh:
-                    pickle.dump({"columns": columns, "rows": rows}, fh, protocol=2)
+                table = _load_window_cache(windowsPickle, rip)
+            clock.lap("window cache")
+        else:
+            zero = None
+            try:
+                if sharded:
+                    same = querySeq == args.hostSeq and resident_names is not None
+                    table, failed = D.scan_sharded(hp.engine, querySeq, w, inc, rip=rip, scaffolds_all=all_,
+                                                   resident_names=resident_names if same else None)
+                    if failed:
+                        zero = ZeroDivisionError("float division by zero")          # on EVERY rank (L437)
+                else:
+                    table, _res = hp.scanTable(args, querySeq)
+            except ZeroDivisionError as err:
+                zero, table = err, getattr(err, "table", None)
+            clock.lap("phase B (scan)")
+            if rank == 0 and table is not None:
+                # the reference writes and prints row by row (L1487-1494): what it had written before dying is written here too
+                write_table(os.path.join(args.tempDir, args.outfile), table)
+                clock.lap("score table text")
+            if zero is not None:
+                raise zero
+            if rank == 0:
+                _dump_window_cache(windowsPickle, table)
+                clock.lap("window pickle")
     finally:
         hp.close()
     if rank != 0:
         return 0
     if args.exitAfter == "WindowKLD":
         log.info("Finished calculating window KLD scores. Exiting.")
+        clock.report()
         return 0
 
     # ---- thresholds and features (L1522-1530, L1671-1707)
-    allKLD = np.array([[float(r[3])] for r in rows], dtype=float)
+    kld = np.where(table.kld_is_int0 != 0, 0.0, table.kld)
     with np.errstate(divide="ignore"):
-        logKLD = np.log10(allKLD)
+        logKLD = np.log10(kld.reshape(-1, 1))
     threshold, _bins = pp.setKLDThresh(args, logKLD)
     threshold = float(np.ravel(threshold)[0])
     log.info("log10(KLD) threshold = %s", threshold)
     if args.hmmKLD:                                                     # L1537-1548
         from .hmm import hmm2BED, hmmBED2GFF
-        intervals, _model = hmm2BED(rows)
+        intervals, _model = hmm2BED(table)
         with open(os.path.join(args.tempDir, args.hmmOutfile), "w") as fh:
             for line in hmmBED2GFF(intervals):
                 fh.write(line)
     if args.runProjection:                                              # L1556-1596: counts for the projection
         from .fasta import readFasta
         from .projection import symmetricCounts
-        feats, _ = pp.thresholdKLD(rows, threshold, args, merge=(args.dimReduce == "features"))
+        feats, _ = pp.thresholdKLD(table, threshold, args, merge=(args.dimReduce == "features"))
         names, seqs = readFasta(querySeq)
         fasta = dict(zip(names, seqs))
         labelled = [(":".join([f[0], str(f[1]), str(f[2])]), fasta[f[0]][int(f[1]) - 1:int(f[2])]) for f in feats if f[0] in fasta]
@@ -248,36 +316,20 @@ def _main(argv=None):
                 pickle.dump(anomCounts, fh, protocol=2)
         log.info("Symmetric k-mer proportions of %s anomalous windows computed; the %s projection is not built here.",
                  len(labelled), args.runProjection)
-    anomalies, _sel = pp.thresholdKLD(rows, threshold, args, merge=True)
+    anomalies, _sel = pp.thresholdKLD(table, threshold, args, merge=True)
     log.info("Detected %s features above KLD threshold.", len(anomalies))
     if args.gffOutfile:
         with open(os.path.join(args.tempDir, args.gffOutfile), "w") as fh:
             for line in pp.anomaly2GFF(anomalies, args):
                 fh.write(line)
     if rip:
-        feats = pp.thresholdRIP(rows, args)
+        feats = pp.thresholdRIP(table, args)
         if feats:
             with open(os.path.join(args.tempDir, args.RIPgff), "w") as fh:
                 for line in pp.RIP2GFF(feats):
                     fh.write(line)
         else:
             log.info("No RIP features detected.")
+    clock.lap("thresholds + features")
+    clock.report()
     return 0
-
-
-def _sharded(hp, args, querySeq, rip):
-    """N ranks, one job: frisk_amd.distributed.run_sharded_files (every rank reads the FASTA natively and takes an
-    equal share of the positions and of the candidate windows); returns rows (rank 0) in table form."""
-    from .distributed import run_sharded_files
-    rows = run_sharded_files(hp.engine, args.hostSeq, args.windowlen, args.increment, mask_host=args.maskHost, rip=rip,
-                             scaffolds_all=args.scaffoldsAll, query_path=querySeq)
-    if rows is None:
-        return None
-    from . import _ffi
-    out = []
-    for r in rows:
-        if r[3] & _ffi.ROW_ZERO_WEIGHT:
-            raise ZeroDivisionError("float division by zero")
-        kld = 0 if (r[3] & _ffi.ROW_NO_MAXMER) else r[4]
-        out.append((r[0], r[1], r[2], kld, r[5]) + tuple(r[6:]))
-    return out

@@ -125,6 +125,28 @@ def hmm2BED(rows, model=None):
     """rows: (name, start, stop, KLD, ...) in table order.  Fits the model on all non-NaN scores stacked
     (L1541), decodes per scaffold, and returns intervals (name, start, stop, 'State1'|'State2') as STRINGS
     sorted the way the reference sorts them - lexicographically on the string fields (L783)."""
+    if hasattr(rows, "kld"):            # a ScoreTable: group by scaffold on the columns
+        t = rows
+        kld = np.where(t.kld_is_int0 != 0, 0.0, t.kld)
+        ok = np.nonzero(~np.isnan(kld))[0]
+        if model is None:
+            model = GaussianHMM2().fit(kld[ok])
+        out = []
+        seq = t.seq_index[ok]
+        order = []                      # scaffolds in order of first appearance (L770-775)
+        seen = set()
+        for sidx in seq[np.sort(np.unique(seq, return_index=True)[1])].tolist():
+            if t.names[sidx] not in seen:
+                seen.add(t.names[sidx])
+                order.append(t.names[sidx])
+        name_of = np.asarray(t.names, dtype=object)[seq]
+        for name in order:
+            rr = ok[name_of == name]
+            states = model.predict(kld[rr])
+            for value, label in ((0, "State1"), (1, "State2")):
+                for a, b in state_runs(states.tolist(), value):
+                    out.append((str(name), str(int(t.start[rr[a]])), str(int(t.stop[rr[b]])), label))
+        return sorted(out, key=lambda x: (x[0], x[1], x[2])), model
     good = [r for r in rows if not (isinstance(r[3], float) and r[3] != r[3])]
     if model is None:
         model = GaussianHMM2().fit(np.array([float(r[3]) for r in good]))

@@ -79,14 +79,22 @@ class HotPath:
         sym, tl, ex, nn = e.profile_get()
         return profileToMaps(sym, tl, ex, nn, self.kMin, self.kMax)
 
+    def profileMaps(self):
+        """The finished profile on the device in the reference's pickled form (list of dicts + 3 metadata dicts, L356-359)."""
+        sym, tl, ex, nn = self.engine.profile_get()
+        return profileToMaps(sym, tl, ex, nn, self.kMin, self.kMax)
+
     def setGenomeProfile(self, genomeKmers):
         """Install a previously computed profile (replaces pickle.load at L1437-1439)."""
         sym, tl, ex, nn = mapsToProfile(genomeKmers, self.kMin, self.kMax)
         self.engine.profile_set(sym, tl, ex, nn)
 
     # phase B -----------------------------------------------------------------------------------
-    def scanGenome(self, args, querySeq, debug=False):
-        """The loop L1478-1494.  Returns (rows, result): rows = list of tuples in output order."""
+    def scanTable(self, args, querySeq, debug=False):
+        """The loop L1478-1494 as columns: returns (ScoreTable of the rows the reference emits, raw ScanResult).
+        Where the reference would die with ZeroDivisionError (L437) this raises it too, with `err.table` = the rows the
+        reference had already written before the failing window."""
+        from .table import ScoreTable
         self._load(querySeq)
         rip = bool(getattr(args, "RIP", False)) and args.minWordSize <= 2
         if rip and args.maxWordSize < 2:
@@ -96,20 +104,21 @@ class HotPath:
                                scaffolds_all=bool(getattr(args, "scaffoldsAll", False)), debug=debug, pinned=False)
         kept = np.nonzero(res.kept)[0]
         bad = kept[(res.status[kept] & _ffi.ROW_ZERO_WEIGHT) != 0]
-        rows = []
-        stop_at = int(bad[0]) if bad.size else None
-        for r in kept.tolist():
-            if stop_at is not None and r >= stop_at:
-                break
-            name = self.names[int(res.seq_index[r])]
-            kld = 0 if (res.status[r] & _ffi.ROW_NO_MAXMER) else float(res.kld[r])   # int 0: empty sum, L465
-            row = (name, int(res.start[r]), int(res.stop[r]), kld, float(res.gc[r]))
-            if rip:
-                row += (float(res.pi[r]), float(res.si[r]), float(res.cri[r]))
-            rows.append(row)
-        if stop_at is not None and not getattr(args, "tolerateZeroWeight", False):
+        tolerate = bool(getattr(args, "tolerateZeroWeight", False))
+        if bad.size:                                    # the reference has written every row before the failing one
+            kept = kept[kept < int(bad[0])]
+        int0 = ((res.status[kept] & _ffi.ROW_NO_MAXMER) != 0).astype(np.uint8)     # int 0: empty sum, L465
+        table = ScoreTable(self.names, res.seq_index[kept], res.start[kept], res.stop[kept], res.kld[kept], res.gc[kept],
+                           res.pi[kept] if rip else None, res.si[kept] if rip else None, res.cri[kept] if rip else None, int0)
+        if bad.size and not tolerate:
             err = ZeroDivisionError("float division by zero")   # what the reference raises at L437
-            err.rows = rows
+            err.table = table
+            err.rows = table.rows() if len(table) <= 100000 else None
             err.result = res
             raise err
-        return rows, res
+        return table, res
+
+    def scanGenome(self, args, querySeq, debug=False):
+        """The same as a list of row tuples (tests, small jobs): (rows, result)."""
+        table, res = self.scanTable(args, querySeq, debug=debug)
+        return table.rows(), res

@@ -137,12 +137,20 @@ def thresholdKLD(table, threshold, args, merge=True):
     """Windows whose log10(KLD) is >= threshold (<= with --findSelf), sorted by (name, start, stop), merged with
     `-d mergeDist -c 4,4,4 -o max,min,mean` (L647-662).  table: list of rows (name, start, stop, KLD, ...).
     Returns (features, selected_rows)."""
-    rows = [r for r in table if not (isinstance(r[3], float) and r[3] != r[3])]
-    rows.sort(key=lambda r: (r[0], r[1], r[2]))
-    with np.errstate(divide="ignore", invalid="ignore"):
-        logs = np.log10(np.array([float(r[3]) for r in rows], dtype=float)) if rows else np.zeros(0)
-    pick = (logs <= threshold) if getattr(args, "findSelf", False) else (logs >= threshold)
-    chosen = [r for r, p in zip(rows, pick) if p]
+    if hasattr(table, "kld"):           # a ScoreTable: select on the columns, make tuples of the chosen rows only
+        kld = np.where(table.kld_is_int0 != 0, 0.0, table.kld)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            logs = np.log10(kld)
+        pick = (logs <= threshold) if getattr(args, "findSelf", False) else (logs >= threshold)
+        chosen = table.rows(np.nonzero(pick & ~np.isnan(kld))[0])
+        chosen.sort(key=lambda r: (r[0], r[1], r[2]))
+    else:
+        rows = [r for r in table if not (isinstance(r[3], float) and r[3] != r[3])]
+        rows.sort(key=lambda r: (r[0], r[1], r[2]))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            logs = np.log10(np.array([float(r[3]) for r in rows], dtype=float)) if rows else np.zeros(0)
+        pick = (logs <= threshold) if getattr(args, "findSelf", False) else (logs >= threshold)
+        chosen = [r for r, p in zip(rows, pick) if p]
     recs = [(r[0], int(r[1]), int(r[2]), float(r[3])) for r in chosen]
     if merge:
         feats = merge_intervals(recs, dist=getattr(args, "mergeDist", 0), ops=("max", "min", "mean"), cols=(3, 3, 3))
@@ -170,10 +178,19 @@ def thresholdRIP(table, args):
     """RIP features (L692-720): windows with PI >= minPI, SI <= maxSI, CRI >= minCRI are merged
     (`-d 0 -c 4,5,6,7,7 -o max,min,max,min,max`) and kept if they overlap at least one window with
     CRI >= peakCRI (`window -w 0 -u`).  table rows: (name, start, stop, KLD, GC, PI, SI, CRI)."""
-    ok = [r for r in table if not any(isinstance(v, float) and v != v for v in (r[3], r[5], r[6], r[7]))]
-    ok.sort(key=lambda r: (r[0], r[1], r[2]))
-    basic = [r for r in ok if r[5] >= args.minPI and r[6] <= args.maxSI and r[7] >= args.minCRI]
-    peaks = [r for r in ok if r[7] >= args.peakCRI]
+    if hasattr(table, "kld"):           # a ScoreTable: filter on the columns first (RIP features are rare)
+        with np.errstate(invalid="ignore"):
+            ok_m = ~(np.isnan(table.kld) | np.isnan(table.pi) | np.isnan(table.si) | np.isnan(table.cri))
+            basic_m = ok_m & (table.pi >= args.minPI) & (table.si <= args.maxSI) & (table.cri >= args.minCRI)
+            peak_m = ok_m & (table.cri >= args.peakCRI)
+        key = lambda r: (r[0], r[1], r[2])      # noqa: E731
+        basic = sorted(table.rows(np.nonzero(basic_m)[0]), key=key)
+        peaks = sorted(table.rows(np.nonzero(peak_m)[0]), key=key)
+    else:
+        ok = [r for r in table if not any(isinstance(v, float) and v != v for v in (r[3], r[5], r[6], r[7]))]
+        ok.sort(key=lambda r: (r[0], r[1], r[2]))
+        basic = [r for r in ok if r[5] >= args.minPI and r[6] <= args.maxSI and r[7] >= args.minCRI]
+        peaks = [r for r in ok if r[7] >= args.peakCRI]
     if not basic or not peaks:
         return None
     recs = [(r[0], int(r[1]), int(r[2]), r[3], r[5], r[6], r[7]) for r in basic]

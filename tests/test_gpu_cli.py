@@ -106,3 +106,56 @@ def test_cli_hmm_segmentation_gff(tmp_path):
     intervals, _ = hmm2BED(rows)
     assert "".join(hmmBED2GFF(intervals)) == gff
     assert open(out / "anom.gff3").read().startswith("##gff-version 3")
+
+
+def test_cli_sharded_cache_semantics(tmp_path, monkeypatch):
+    """Under torchrun the CLI keeps the reference's cache semantics (L1436-1447, L1454-1459, L1503-1505): --exitAfter
+    GenomeKmers stops BEFORE any window is scored and leaves the genome pickle (the one file that option exists to
+    produce), equal to the plain run's; a second run reuses both caches; --recalc / --recalcWin force recomputation."""
+    import pickle
+    import torch.distributed as dist
+    from frisk_amd.cli import main
+    c = Case("markov_k6")
+    base = ["-H", c.host, "-k", "6", "-w", "400", "-i", "150", "--RIP"]
+    assert main(base + ["-t", str(tmp_path / "P"), "--exitAfter", "WindowKLD"]) == 0
+    plain_gen = pickle.load(open(tmp_path / "P" / c.doc["genome_pickle_basename"], "rb"))
+    plain_tab = open(tmp_path / "P" / "raw_window_scores.bed").read()
+    for k, v in (("FRISK_FORCE_SHARDED", "1"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"),
+                 ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29643")):
+        monkeypatch.setenv(k, v)
+    S = tmp_path / "S"
+    try:
+        assert main(base + ["-t", str(S), "--exitAfter", "GenomeKmers"]) == 0
+        assert os.path.isfile(S / c.doc["genome_pickle_basename"])
+        assert not os.path.exists(S / "raw_window_scores.bed") and not os.path.exists(S / c.doc["window_pickle_basename"])
+        assert pickle.load(open(S / c.doc["genome_pickle_basename"], "rb")) == plain_gen
+        t_gen = os.path.getmtime(S / c.doc["genome_pickle_basename"])
+        assert main(base + ["-t", str(S), "--exitAfter", "WindowKLD"]) == 0             # profile from the cache, scan sharded
+        assert os.path.getmtime(S / c.doc["genome_pickle_basename"]) == t_gen
+        assert open(S / "raw_window_scores.bed").read() == plain_tab
+        frame = pickle.load(open(S / c.doc["window_pickle_basename"], "rb"))             # a DataFrame, as the reference pickles
+        assert list(frame.columns) == ["name", "start", "stop", "windowKLD", "GC", "PI", "SI", "CRI"] and len(frame) == len(c.rows)
+        os.remove(S / "raw_window_scores.bed")
+        assert main(base + ["-t", str(S), "-F", "0.08", "--gffOutfile", "a.gff3"]) == 0  # both caches: nothing recomputed
+        assert not os.path.exists(S / "raw_window_scores.bed") and os.path.isfile(S / "a.gff3")
+        assert main(base + ["-t", str(S), "--recalc", "--recalcWin", "--exitAfter", "WindowKLD"]) == 0
+        assert os.path.getmtime(S / c.doc["genome_pickle_basename"]) > t_gen
+        assert open(S / "raw_window_scores.bed").read() == plain_tab
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_cli_zero_weight_writes_the_rows_before_the_failure(tmp_path, capsys):
+    """The reference writes and prints each row before scoring the next (L1487-1494): when a window dies with
+    ZeroDivisionError (L437) the table already holds every row before it."""
+    from frisk_amd.cli import main
+    c = Case("hq_m5k6_zero")
+    first_bad = next(i for i, r in enumerate(c.rows) if "error" in r)
+    with pytest.raises(ZeroDivisionError):
+        main(["-H", c.host, "-Q", c.query, "-m", "5", "-k", "6", "-w", "500", "-i", "100", "-t", str(tmp_path / "Z"),
+              "--exitAfter", "WindowKLD"])
+    table = open(tmp_path / "Z" / "raw_window_scores.bed").read().splitlines()
+    assert len(table) == 1 + first_bad
+    assert capsys.readouterr().out.splitlines()[1:] == table[1:]
+    assert not any(f.endswith("KLD_window_500_increment_100.p") for f in os.listdir(tmp_path / "Z"))
