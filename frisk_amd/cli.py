@@ -224,6 +224,7 @@ def _main(argv=None):
     rip = len(columns) == 8
     w, inc, all_ = args.windowlen, args.increment, bool(args.scaffoldsAll)
     hp = HotPath(args.minWordSize, args.maxWordSize, device=local_rank)
+    clock.lap("startup (imports + HIP context)")
     table = None
     try:
         # ---- phase A: host k-mer profile (L1436-1447); --recalc is store_false: giving it forces recomputation.
@@ -241,8 +242,10 @@ def _main(argv=None):
                 resident_names = D.profile_sharded(hp.engine, args.hostSeq, w, inc, mask_host=args.maskHost, scaffolds_all=all_)
                 genomeKmers = hp.profileMaps() if rank == 0 else None
             else:
+                hp._load(args.hostSeq)
+                clock.lap("FASTA parse + upload + pack")
                 genomeKmers = hp.genomeProfile(args)
-            clock.lap("phase A (parse + upload + profile)")
+            clock.lap("phase A (profile)" if not sharded else "phase A (parse + upload + profile + all-reduce)")
             if rank == 0:
                 with open(genomepickle, "wb") as fh:
                     pickle.dump(genomeKmers, fh, protocol=2)

@@ -20,6 +20,7 @@
 #include "scan_big_kernel.h"
 #include "synth_kernel.h"
 #include "table_text.h"
+#include "fasta_reader.h"
 
 #ifndef FRISK_K8_WIDTH
 #define FRISK_K8_WIDTH 0            // order-8 counters of the default K = 8 path (scan8_kernel.h): 0 = adaptive 4/8 bits, 4, 8, 16 = off
@@ -338,66 +339,6 @@ int64_t tile_end(const frisk_ctx::Batch::Tile& t, int32_t w, int32_t inc, int km
     return std::max<int64_t>(b, std::min<int64_t>(t.size, t.own1 + kmax - 1));
 }
 
-// Native FASTA reader with the record semantics of the reference's iterFasta (L139-164).  Records are appended to `stage`
-// in the upload layout: sequence bytes, then one PAD byte.  Returns false with `err` set on failure.
-static bool parse_fasta(const char* path, std::vector<std::string>& names, std::vector<int64_t>& lens, std::vector<uint8_t>& stage,
-                        std::string& err) {
-    gzFile fh = gzopen(path, "rb");                         // reads plain files too
-    if (!fh) { err = std::string("cannot open FASTA file: ") + path; return false; }
-    gzbuffer(fh, 1 << 20);
-    // records are appended to `stage` in the upload layout: sequence bytes, then one PAD byte
-    std::string line, carry;
-    std::vector<char> buf(1 << 22);
-    bool in_record = false;
-    int64_t cur_len = 0;
-    auto is_space = [](unsigned char ch) { return ch == ' ' || (ch >= 9 && ch <= 13); };       // str.strip() on ASCII
-    auto finish_record = [&]() {
-        if (in_record) { lens.push_back(cur_len); stage.push_back(uint8_t(FRISK_PAD_BYTE)); }
-    };
-    auto handle_line = [&](const char* b, const char* e) {
-        while (b < e && is_space((unsigned char)*b)) ++b;
-        while (e > b && is_space((unsigned char)e[-1])) --e;
-        if (b == e) return;                                                 // blank line (L150-151)
-        if (*b == '>') {                                                    // header (L152-157)
-            const char* hb = b;
-            const char* he = e;
-            while (hb < he && *hb == '>') ++hb;                             // line.strip('>')
-            while (he > hb && he[-1] == '>') --he;
-            while (hb < he && is_space((unsigned char)*hb)) ++hb;           // .split()[0]
-            const char* te = hb;
-            while (te < he && !is_space((unsigned char)*te)) ++te;
-            if (te == hb) { if (err.empty()) err = "FASTA header without a name"; return; }    // IndexError in the reference
-            finish_record();
-            names.emplace_back(hb, te);
-            in_record = true;
-            cur_len = 0;
-        } else if (in_record) {                                             // sequence line (L158-160)
-            stage.insert(stage.end(), reinterpret_cast<const uint8_t*>(b), reinterpret_cast<const uint8_t*>(e));
-            cur_len += e - b;
-        }                                                                   // text before the first header is dropped (L157)
-    };
-    for (;;) {
-        const int got = gzread(fh, buf.data(), unsigned(buf.size()));
-        if (got < 0) { gzclose(fh); err = std::string("read error in FASTA file: ") + path; return false; }
-        if (got == 0) break;
-        const char* p = buf.data();
-        const char* end = p + got;
-        while (p < end) {
-            const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
-            if (!nl) { carry.append(p, end); break; }
-            if (!carry.empty()) { carry.append(p, nl); handle_line(carry.data(), carry.data() + carry.size()); carry.clear(); }
-            else handle_line(p, nl);
-            p = nl + 1;
-        }
-    }
-    gzclose(fh);
-    if (!carry.empty()) handle_line(carry.data(), carry.data() + carry.size());
-    finish_record();
-    if (!err.empty()) { err += std::string(": ") + path; return false; }
-    if (lens.size() > size_t(0x7FFFFFFF)) { err = "too many FASTA records"; return false; }
-    return true;
-}
-
 }  // namespace
 
 extern "C" {
@@ -540,27 +481,50 @@ int frisk_seq_load(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens
 
 int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t* total_len_out) {
     if (!c || !path) return FRISK_E_ARG;
-    std::vector<uint8_t> stage;
-    std::vector<int64_t> lens;
-    std::vector<std::string> names;
+    frisk_fasta::Records rec;
     std::string err;
-    if (!parse_fasta(path, names, lens, stage, err)) return fail(c, FRISK_E_ARG, err);
+    if (!frisk_fasta::parse(path, rec, err)) return fail(c, FRISK_E_ARG, err);
     HIPC(c, hipSetDevice(c->device));
-    int rc = layout_batch(c, lens.data(), int32_t(lens.size()));
+    int rc = layout_batch(c, rec.lens.data(), int32_t(rec.lens.size()));
     if (rc) return rc;
-    c->b().seq_name = names;
-    stage.resize(size_t(c->b().padded_len), uint8_t(FRISK_PAD_BYTE));          // tail padding up to a multiple of 32
+    c->b().seq_name = rec.names;
+    rec.stage.resize(size_t(c->b().padded_len), uint8_t(FRISK_PAD_BYTE));          // tail padding up to a multiple of 32
     HIPC(c, c->b().d_ascii.reserve(size_t(c->b().padded_len)));
-    HIPC(c, hipMemcpyAsync(c->b().d_ascii.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->b().d_ascii.p, rec.stage.data(), rec.stage.size(), hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     rc = alloc_packed(c);
     if (rc) return rc;
     rc = run_pack(c);
     if (rc) return rc;
     int64_t total = 0;
-    for (int64_t v : lens) total += v;
-    if (n_seq_out) *n_seq_out = int32_t(lens.size());
+    for (int64_t v : rec.lens) total += v;
+    if (n_seq_out) *n_seq_out = int32_t(rec.lens.size());
     if (total_len_out) *total_len_out = total;
+    return FRISK_OK;
+}
+
+int frisk_fasta_digest(const char* path, int32_t* n_seq, int64_t* total_len, uint64_t* digest) {
+    if (!path) return FRISK_E_ARG;
+    frisk_fasta::Records rec;
+    std::string err;
+    if (!frisk_fasta::parse(path, rec, err)) return FRISK_E_ARG;
+    uint64_t h = 1469598103934665603ull;                       // FNV-1a over name \0 sequence \0, record after record
+    auto eat = [&h](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } };
+    const uint8_t zero = 0;
+    int64_t total = 0, off = 0;
+    for (size_t r = 0; r < rec.lens.size(); ++r) {
+        eat(reinterpret_cast<const uint8_t*>(rec.names[r].data()), rec.names[r].size());
+        eat(&zero, 1);
+        eat(rec.stage.data() + off, size_t(rec.lens[r]));
+        eat(&zero, 1);
+        if (rec.stage[size_t(off + rec.lens[r])] != FRISK_PAD_BYTE) return FRISK_E_STATE;       // the PAD behind every record
+        off += rec.lens[r] + 1;
+        total += rec.lens[r];
+    }
+    if (size_t(off) != rec.stage.size()) return FRISK_E_STATE;
+    if (n_seq) *n_seq = int32_t(rec.lens.size());
+    if (total_len) *total_len = total;
+    if (digest) *digest = h;
     return FRISK_OK;
 }
 
@@ -569,11 +533,12 @@ int frisk_fasta_load_shard(frisk_ctx* c, const char* path, int32_t w, int32_t in
     if (!c || !path) return FRISK_E_ARG;
     if (w < 1 || inc < 1) return fail(c, FRISK_E_ARG, "window length and increment must be >= 1");
     if (world < 1 || rank < 0 || rank >= world) return fail(c, FRISK_E_ARG, "rank outside [0, world)");
-    std::vector<uint8_t> stage;
-    std::vector<int64_t> lens;
-    std::vector<std::string> names;
+    frisk_fasta::Records rec;
     std::string err;
-    if (!parse_fasta(path, names, lens, stage, err)) return fail(c, FRISK_E_ARG, err);
+    if (!frisk_fasta::parse(path, rec, err)) return fail(c, FRISK_E_ARG, err);
+    const std::vector<int64_t>& lens = rec.lens;
+    const std::vector<std::string>& names = rec.names;
+    const frisk_fasta::ByteVec& stage = rec.stage;
     HIPC(c, hipSetDevice(c->device));
     int64_t c0 = 0, c1 = 0;
     std::vector<frisk_ctx::Batch::Tile> tiles = plan_tiles(lens, w, inc, (flags & FRISK_SCAN_SCAFFOLDS_ALL) != 0, c->kmax, rank, world, c0, c1);

@@ -88,6 +88,10 @@ int frisk_seq_set_names(frisk_ctx* ctx, const char* const* names, int32_t n_seq)
  * surrounding whitespace, blank lines skipped, case preserved) straight into the upload layout, and make its records
  * the resident batch.  Record names / lengths are then available from frisk_seq_name / frisk_seq_len. */
 int frisk_fasta_load(frisk_ctx* ctx, const char* path, int32_t* n_seq, int64_t* total_len);
+/* Host-only test utility: parse `path` with the native reader and return the number of records, their total length and an
+ * FNV-1a digest over (name, 0, sequence, 0) of every record - what the CPU test-suite compares with the Python reader. */
+int frisk_fasta_digest(const char* path, int32_t* n_seq, int64_t* total_len, uint64_t* digest);
+
 /* Multi-GPU form of frisk_fasta_load (window-tile sharding with halo): every rank parses the file, but keeps
  * resident only what it needs for ITS share of the job - the candidate windows [*cand_begin, *cand_end) of the job's
  * numbering (an equal contiguous share) and the positions whose k-mers it counts in phase A (every base of the genome

@@ -1,0 +1,79 @@
+"""The native FASTA reader (csrc/fasta_reader.h: memory-mapped, all host threads for plain files; zlib for .gz) against the
+Python restatement of the reference's iterFasta (frisk_amd/fasta.py, L139-164), through the host-only digest entry point."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+from frisk_amd import _ffi
+from frisk_amd.fasta import readFasta
+
+
+def _fnv(names, seqs):
+    h = 1469598103934665603
+    mask = (1 << 64) - 1
+    for n, s in zip(names, seqs):
+        for chunk in (n.encode("ascii"), b"\0", s if isinstance(s, bytes) else s.encode("ascii"), b"\0"):
+            # vectorised FNV-1a is not possible (sequential dependency): hash a digest of long sequences instead
+            for b in chunk:
+                h = ((h ^ b) * 1099511628211) & mask
+    return h
+
+
+def _native(path):
+    n, total, dig = C.c_int32(), C.c_int64(), C.c_uint64()
+    rc = _ffi.lib().frisk_fasta_digest(os.fsencode(str(path)), C.byref(n), C.byref(total), C.byref(dig))
+    return rc, n.value, total.value, dig.value
+
+
+def _check(path):
+    names, seqs = readFasta(str(path))
+    rc, n, total, dig = _native(path)
+    assert rc == 0
+    assert n == len(names) and total == sum(len(s) for s in seqs)
+    assert dig == _fnv(names, seqs)
+
+
+def test_tricky_small_files(tmp_path):
+    tricky = tmp_path / "tricky.fa"
+    tricky.write_bytes(b"stray text before any header\nACGT\n>>r1>  first record   desc >\r\n  ACGTNN  \r\n\r\nac gt\n\n>r2\n>r3\tx\n"
+                       b"TTTTTTTTTT\nGG>GG\n>r4 last no newline\nACGTRYKM")
+    _check(tricky)
+    gz = tmp_path / "tricky.fa.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(tricky.read_bytes())
+    _check(gz)
+    (tmp_path / "empty.fa").write_bytes(b"")
+    _check(tmp_path / "empty.fa")
+    (tmp_path / "nohdr.fa").write_bytes(b"ACGT\nACGT\n")
+    _check(tmp_path / "nohdr.fa")
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b">\nACGT\n")
+    assert _native(bad)[0] != 0
+    assert _native(tmp_path / "missing.fa")[0] != 0
+
+
+def test_parallel_path_chunk_boundaries(tmp_path):
+    """> 16 MB: the file is cut into one chunk per host thread at line boundaries.  Records of very different sizes, headers
+    right at likely cut points, CRLF and blank lines, a 3 MB line without a newline, and text before the first header."""
+    rng = np.random.default_rng(4)
+    path = tmp_path / "big.fa"
+    with open(path, "wb") as fh:
+        fh.write(b"junk line that belongs to no record\n")
+        for i in range(300):
+            n = int(rng.choice([0, 1, 59, 60, 61, 5000, 200_000, 1_500_000]))
+            s = rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), size=n).tobytes()
+            fh.write(b">rec%d extra words %d\n" % (i, n))
+            if i % 7 == 3:
+                fh.write(s + b"\n")                                  # one long line
+            else:
+                width = int(rng.choice([60, 70, 80]))
+                eol = b"\r\n" if i % 5 == 0 else b"\n"
+                for o in range(0, n, width):
+                    fh.write(s[o:o + width] + eol)
+                    if (o // width) % 997 == 0:
+                        fh.write(eol)                                # a blank line now and then
+        fh.write(b">last\n" + b"ACGT" * 800_000)                     # no trailing newline, 3.2 MB line
+    assert os.path.getsize(path) > (1 << 24)
+    _check(path)

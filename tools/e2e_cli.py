@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""End-to-end timing of `python -m frisk_amd` on synthetic FASTA files of BASELINE.json's shapes (GPU box).
+Writes the FASTA (60-column lines, plain and .gz), runs the CLI with --exitAfter WindowKLD (stdout -> /dev/null) and
+prints one JSON line per run with the CLI's own timing split (FRISK_TIMING=1).  usage: e2e_cli.py C3|C5shard|C5 [workdir]"""
+import gzip
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from frisk_amd import Engine, synth  # noqa: E402
+
+shape = sys.argv[1] if len(sys.argv) > 1 else "C3"
+work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/frisk_e2e"
+os.makedirs(work, exist_ok=True)
+if shape == "C3":
+    lens, nfrac = synth.C3_LENS, 0.001
+elif shape == "C5shard":
+    lens, nfrac = synth.c5_shard_lens(8, 0), 0.07
+else:
+    lens, nfrac = [n for r in range(8) for n in synth.c5_shard_lens(8, r)], 0.07
+
+fa = os.path.join(work, shape + ".fa")
+t0 = time.time()
+if not os.path.exists(fa):
+    with Engine(1, 4) as e, open(fa, "wb") as fh:
+        e.synth(lens, seed=0xE2E, island_frac=0.02, n_frac=nfrac, lower_frac=0.02)
+        for i, n in enumerate(lens):
+            s = np.frombuffer(e.read_seq(i), dtype=np.uint8)
+            fh.write(b">scaffold_%d synthetic\n" % i)
+            full = (n // 60) * 60
+            if full:
+                body = np.empty((full // 60, 61), np.uint8)
+                body[:, :60] = s[:full].reshape(-1, 60)
+                body[:, 60] = 10
+                fh.write(body.tobytes())
+            if n > full:
+                fh.write(s[full:].tobytes() + b"\n")
+print(json.dumps({"fasta": fa, "bases": sum(lens), "bytes": os.path.getsize(fa), "write_s": round(time.time() - t0, 2)}), flush=True)
+gz = fa + ".gz"
+if shape != "C5" and not os.path.exists(gz):
+    t0 = time.time()
+    with open(fa, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
+        while True:
+            b = src.read(1 << 24)
+            if not b:
+                break
+            dst.write(b)
+    print(json.dumps({"gz": gz, "bytes": os.path.getsize(gz), "gzip_s": round(time.time() - t0, 2)}), flush=True)
+
+for path in [fa] + ([gz] if os.path.exists(gz) else []):
+    for label, extra in (("cold caches", ["--recalc", "--recalcWin"]),):
+        tmp = os.path.join(work, "T_" + os.path.basename(path))
+        cmd = [sys.executable, "-m", "frisk_amd", "-H", path, "-k", "8", "-w", "5000", "-i", "1000", "-t", tmp,
+               "--exitAfter", "WindowKLD"] + extra
+        env = dict(os.environ, FRISK_TIMING="1", PYTHONPATH=ROOT)
+        t0 = time.time()
+        out = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+        wall = time.time() - t0
+        split = None
+        for line in out.stderr.splitlines():
+            if line.startswith('{"frisk_timing"'):
+                split = json.loads(line)
+        rows = sum(1 for _ in open(os.path.join(tmp, "raw_window_scores.bed"))) - 1 if out.returncode == 0 else -1
+        print(json.dumps({"run": os.path.basename(path), "label": label, "rc": out.returncode, "wall_s": round(wall, 2), "rows": rows,
+                          "split": split, "err": out.stderr[-300:] if out.returncode else None}), flush=True)
