@@ -22,6 +22,9 @@
 #include "table_text.h"
 #include "fasta_reader.h"
 
+#ifndef FRISK_K7_WPS
+#define FRISK_K7_WPS 4              // waves per SIMD (= 256-thread workgroups per CU) of the K = 6, 7 narrow-counter kernels
+#endif
 #ifndef FRISK_K8_WIDTH
 #define FRISK_K8_WIDTH 0            // order-8 counters of the default K = 8 path (scan8_kernel.h): 0 = adaptive 4/8 bits, 4, 8, 16 = off
 #endif
@@ -76,6 +79,7 @@ struct frisk_ctx {
             int32_t kind;               // as ScafDesc::kind
             int64_t own0, own1;         // [own0, own1): scaffold positions whose k-mers THIS rank counts in phase A
         };
+        int width_hint = 0, hint_w = 0, hint_inc = 0;   // counter width the last sampled scan of this batch chose (0: none yet)
         bool tiled = false;
         std::vector<Tile> tiles;
         int32_t tile_w = 0, tile_inc = 0;
@@ -159,6 +163,7 @@ int layout_batch(frisk_ctx* c, frisk_ctx::Batch& B, const int64_t* lens, int32_t
     if (B.padded_len == 0) B.padded_len = 32;
     B.n_seq = n_seq;
     B.have_seq = false;
+    B.width_hint = 0;
     B.tiled = false;
     B.tiles.clear(); B.g_name.clear(); B.g_len.clear();
     return FRISK_OK;
@@ -237,19 +242,31 @@ hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st
     return hipGetLastError();
 }
 
-template <int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
+template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
 hipError_t launch_scan8(const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
     constexpr int wg_per_cu = WPS * 256 / NT;
-    static_assert(Lds8<BITS, LOGN, NT>::total * wg_per_cu <= 160 * 1024, "the workgroups meant to share a CU must fit its LDS");
+    static_assert(Lds8<KMAX, BITS, LOGN, NT>::total * wg_per_cu <= 160 * 1024, "the workgroups meant to share a CU must fit its LDS");
     int grid = int(std::max<int64_t>(1, std::min<int64_t>(work_items, int64_t(num_cu) * wg_per_cu)));
     if (grid >= 8) grid &= ~7;
-    scan8_kernel<NT, ITS, BITS, LOGN, WPS, DEBUG><<<grid, NT, 0, st>>>(P);      // LDS is static (Lds8)
+    scan8_kernel<KMAX, NT, ITS, BITS, LOGN, WPS, DEBUG><<<grid, NT, 0, st>>>(P);      // LDS is static (Lds8)
     return hipGetLastError();
 }
 
 // one launch of the narrow-counter K = 8 kernel: counter width, window class (<= 2048 / <= 5120 bases), debug dump
-hipError_t launch_narrow(int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
-#define FRISK_L8(ITS_, BITS_, WPS_, DBG_) return launch_scan8<256, ITS_, BITS_, 64, WPS_, DBG_>(P, num_cu, work_items, st)
+hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
+#define FRISK_L7(K_, ITS_, DBG_) return launch_scan8<K_, 256, ITS_, 8, 64, FRISK_K7_WPS, DBG_>(P, num_cu, work_items, st)
+    if (kmax == 7) {        // K = 6, 7: the 8-bit table is 16 / 4 KiB - registers, not LDS, bound the workgroups per CU
+        if (debug) { if (small_w) FRISK_L7(7, 8, true); else FRISK_L7(7, 20, true); }
+        if (small_w) FRISK_L7(7, 8, false);
+        FRISK_L7(7, 20, false);
+    }
+    if (kmax == 6) {
+        if (debug) { if (small_w) FRISK_L7(6, 8, true); else FRISK_L7(6, 20, true); }
+        if (small_w) FRISK_L7(6, 8, false);
+        FRISK_L7(6, 20, false);
+    }
+#undef FRISK_L7
+#define FRISK_L8(ITS_, BITS_, WPS_, DBG_) return launch_scan8<8, 256, ITS_, BITS_, 64, WPS_, DBG_>(P, num_cu, work_items, st)
     if (bits == 4) {
         if (debug) { if (small_w) FRISK_L8(8, 4, 3, true); else FRISK_L8(20, 4, 3, true); }
         if (small_w) FRISK_L8(8, 4, 3, false);
@@ -983,7 +1000,10 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     int width = FRISK_K8_WIDTH;
     if (const char* ev = tune_env("FRISK_K8_BITS")) width = std::atoi(ev);
     // (decided by -w alone: rescued small scaffolds beyond the kernel's reach are handed on per window, see scan8_kernel.h)
-    const bool narrow = k8 && c->kmin <= 5 && w <= 5120 && c->plan_maxwin <= 65535 && (width == 0 || width == 4 || width == 8) && !quart;
+    const bool narrow8 = k8 && c->kmin <= 5 && w <= 5120 && c->plan_maxwin <= 65535 && (width == 0 || width == 4 || width == 8) && !quart;
+    // K = 6, 7: the same kernel with 8-bit counters (a K-mer must occur 256 times in a window to wrap one)
+    const bool narrow7 = (c->kmax == 6 || c->kmax == 7) && c->kmin <= c->kmax - 3 && w <= 5120 && c->plan_maxwin <= 65535 && width != 16;
+    const bool narrow = narrow8 || narrow7;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
     if (c->plan_maxwin > 65535) {
@@ -1015,12 +1035,16 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
         ScanParams B = P;                       // the bulk launch over [c0, c1)
         B.chunk = int32_t(chunk8);
-        int bulk = (width == 4) ? 4 : 8;
-        if (width == 0 && !debug && nchunks >= 64 * B.sel_mod) {
+        int bulk = (width == 4 && narrow8) ? 4 : 8;
+        frisk_ctx::Batch& RB = c->b();
+        const bool hinted = RB.width_hint != 0 && RB.hint_w == w && RB.hint_inc == inc;
+        if (narrow7) { /* 8-bit bulk, no sample */ }
+        else if (width == 0 && !debug && hinted) bulk = RB.width_hint;      // same batch, same geometry: the earlier sample still holds
+        else if (width == 0 && !debug && nchunks >= 64 * B.sel_mod) {
             ScanParams S = B;                   // the sample
             S.sel_mode = 1; S.out_list = c->d_ovf_list.p; S.out_count = c->d_ovf_count.p;
             const int64_t nsample = (nchunks + S.sel_mod - 1) / S.sel_mod;
-            HIPC(c, launch_narrow(4, small_w, false, S, c->num_cu, nsample, c->stream));
+            HIPC(c, launch_narrow(c->kmax, 4, small_w, false, S, c->num_cu, nsample, c->stream));
             unsigned int handed = 0;
             HIPC(c, hipMemcpyAsync(&handed, c->d_ovf_count.p, sizeof(handed), hipMemcpyDeviceToHost, c->stream));
             HIPC(c, hipStreamSynchronize(c->stream));
@@ -1028,27 +1052,36 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
             // 4-bit counters, 27.5 ns with 8-bit; redoing costs another 27.5)
             bulk = (double(handed) <= 0.2 * double(nsample * chunk8)) ? 4 : 8;
             B.sel_mode = 2;
+            RB.width_hint = bulk; RB.hint_w = w; RB.hint_inc = inc;
         }
         if (bulk == 4) { B.out_list = c->d_ovf_list.p; B.out_count = c->d_ovf_count.p; }
         else { B.out_list = c->d_ovf_list2.p; B.out_count = c->d_ovf_count.p + 1; }
         const int64_t bulk_chunks = B.sel_mode == 2 ? nchunks - (nchunks + B.sel_mod - 1) / B.sel_mod : nchunks;
-        HIPC(c, launch_narrow(bulk, small_w, debug, B, c->num_cu, bulk_chunks, c->stream));
+        HIPC(c, launch_narrow(c->kmax, bulk, small_w, debug, B, c->num_cu, bulk_chunks, c->stream));
         c->scan_stat[0] = bulk;
         if (bulk == 4 || B.sel_mode == 2) {     // list 1 (4-bit hand-overs, the sample's included) -> 8-bit -> list 2
             ScanParams H = P;
             H.in_list = c->d_ovf_list.p; H.in_count = c->d_ovf_count.p;
             H.out_list = c->d_ovf_list2.p; H.out_count = c->d_ovf_count.p + 1;
-            HIPC(c, launch_narrow(8, small_w, debug, H, c->num_cu, n, c->stream));
+            HIPC(c, launch_narrow(c->kmax, 8, small_w, debug, H, c->num_cu, n, c->stream));
         }
         // list 2 -> 16-bit counters, one window per workgroup at a time (a no-op when the list is empty)
         P.in_list = c->d_ovf_list2.p; P.in_count = c->d_ovf_count.p + 1;
         grid = int(std::min<int64_t>(n, int64_t(c->num_cu)));
         if (grid >= 8) grid &= ~7;
-        if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
-        else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
-        else if (its == 10) FRISK_LAUNCH(512, true, 10, false);
-        else if (its == 16) FRISK_LAUNCH(512, true, 16, false);
-        else FRISK_LAUNCH(1024, true, 0, false);
+        if (k8) {
+            if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
+            else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
+            else if (its == 10) FRISK_LAUNCH(512, true, 10, false);
+            else if (its == 16) FRISK_LAUNCH(512, true, 16, false);
+            else FRISK_LAUNCH(1024, true, 0, false);
+        } else {
+            if (debug) { if (its) FRISK_LAUNCH(512, false, 16, true); else FRISK_LAUNCH(1024, false, 0, true); }
+            else if (its == 4) FRISK_LAUNCH(512, false, 4, false);
+            else if (its == 10) FRISK_LAUNCH(512, false, 10, false);
+            else if (its == 16) FRISK_LAUNCH(512, false, 16, false);
+            else FRISK_LAUNCH(1024, false, 0, false);
+        }
     } else if (k8 && !debug && quart) {
         // K = 8 with TWO independent 256-thread workgroups per CU: the order-8 table serves one leading base at a time
         // (32 KiB), the window's max-mers are bucketed by leading base and handled in four passes (scan_kernel.h, QUART)

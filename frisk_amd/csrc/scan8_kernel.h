@@ -32,23 +32,25 @@
 #endif
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
-enum { M8_TSUM = 6 };              // misc slot: grand total of the order-8 table (overflow check)
+enum { M8_TSUM = 6,                // misc slots: grand total of the order-8 table (overflow check) ...
+       M8_SAFE = 7 };              // ... and the code of SOME max-mer of the window (what lanes without one score instead)
 
 // LDS carve-up, all compile-time: the kernels declare it as ONE static array, so every table address is a constant that
 // folds into the 16-bit offset field of the ds_ instructions (a dynamic `extern __shared__` base costs one VALU add per
 // address).  The 32 / 64 KiB order-8 table comes LAST: its own offset is then the only large one, and it is an immediate.
-template <int BITS, int LOGN, int NT>
+template <int KMAX, int BITS, int LOGN, int NT>
 struct Lds8 {
     static constexpr uint32_t small = 0;
-    static constexpr uint32_t small_bytes = 2736;                                  // orders kmin..5 as u16 bins, sized for kmin = 1
+    static constexpr uint32_t small_bytes = 2736;                                  // orders kmin..KMAX-3 as u16 bins (sized for 1..5)
     static constexpr uint32_t orphans = small + small_bytes;                       // u16[FRISK8_ORPH_CAP]
-    static constexpr uint32_t pre_i = (orphans + FRISK8_ORPH_CAP * 2 + 15) / 16 * 16;   // f64[1024]: shared prefix (level 5) ...
-    static constexpr uint32_t pre_w = pre_i + 1024 * 8;                            // ... and u32[1024], as in scan_kernel.h
-    static constexpr uint32_t logtab = pre_w + 1024 * 4;                           // {1/c_i, -ln(1/c_i)} x LOGN
+    static constexpr uint32_t NL = 1u << (2 * (KMAX - 3));                         // entries of the shared prefix tables (level KMAX-3)
+    static constexpr uint32_t pre_i = (orphans + FRISK8_ORPH_CAP * 2 + 15) / 16 * 16;   // f64[NL]: shared prefix sums ...
+    static constexpr uint32_t pre_w = pre_i + NL * 8;                              // ... and u32[NL], as in scan_kernel.h
+    static constexpr uint32_t logtab = pre_w + NL * 4;                             // {1/c_i, -ln(1/c_i)} x LOGN
     static constexpr uint32_t rctab = logtab + uint32_t(LOGN) * 16;                // 1/c for c < 16
     static constexpr uint32_t misc = rctab + 16 * 8;                               // counters x2, then one {Sw, Sg, T} per wave
     static constexpr uint32_t t8 = (misc + 2 * FRISK8_SLOTS * 4 + uint32_t(NT / 64) * 3 * 8 + 15) / 16 * 16;
-    static constexpr uint32_t t8_bytes = 65536u * BITS / 8;
+    static constexpr uint32_t t8_bytes = (1u << (2 * KMAX)) * BITS / 8;
     static constexpr uint32_t total = t8 + t8_bytes;
 };
 
@@ -82,8 +84,11 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
 
 // NT threads, windows of at most NT*ITS bases, BITS per order-8 counter, LOGN: bins of the logarithm table, WPS: waves per SIMD the register allocation must allow (= workgroups per
 // CU * NT / 256).
-template <int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
+template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
 __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
+    static_assert(KMAX >= 6 && KMAX <= 8, "highest order 6, 7 or 8");
+    constexpr int K = KMAX, LVL = KMAX - 3;              // highest order; level of the shared prefix tables (and of the small tables' top)
+    constexpr uint32_t NK = 1u << (2 * K), NL = 1u << (2 * LVL);
     static_assert(BITS == 4 || BITS == 8, "order-8 counters are 4 or 8 bits wide");
     static_assert(LOGN == 32 || LOGN == 64 || LOGN == 128, "logarithm table of 32, 64 or 128 bins");
     constexpr int LOGDEG = LOGN == 128 ? 5 : (LOGN == 64 ? 6 : 7);   // |r| < 2^-8 / 2^-7 / 2^-6: truncation r^(DEG+1)/(DEG+1) < 6e-16
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     constexpr int NW = NT / 64;
     constexpr int SHW = BITS == 8 ? 2 : 3;               // code >> SHW = dword of the table
     constexpr uint32_t PERM = (32 / BITS) - 1;           // code & PERM = field inside the dword
-    using L = Lds8<BITS, LOGN, NT>;
+    using L = Lds8<KMAX, BITS, LOGN, NT>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[L::total];
     const int tid0 = threadIdx.x;
     const int kmin0 = P.kmin;
@@ -215,10 +220,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const int nleft = n - j0;
             const uint32_t actm = topbits(nleft) & MINE;
             const uint32_t vld = ~ainv;
-            uint32_t fullm = vld;                                            // 8 valid bases from here on ...
-            fullm &= fullm << 1; fullm &= fullm << 2; fullm &= fullm << 4;
-            fullm &= topbits(nleft - 7) & MINE;                              // ... all inside the window: a max-mer starts here
-            auto code_at = [&](int it) -> uint32_t { return uint32_t(acode >> (48 - 2 * it)) & 0xFFFFu; };
+            uint32_t fullm = vld;                                            // K valid bases from here on ...
+            fullm &= fullm << 1; fullm &= fullm << 2;                        // (4 in a row)
+            fullm &= fullm << (K - 4);                                       // (K = 6, 7, 8 in a row)
+            fullm &= topbits(nleft - (K - 1)) & MINE;                        // ... all inside the window: a max-mer starts here
+            auto code_at = [&](int it) -> uint32_t { return uint32_t(acode >> (64 - 2 * K - 2 * it)) & (NK - 1u); };     // the K-mer at position it
             {
                 uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
                 auto tally = [&](bool sel, uint32_t c2) {
@@ -240,15 +246,16 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         int run = lead_clear8((ainv >> (24 - it)) & 0xFFu);
                         const int rem = n - (j0 + it);
                         run = run < rem ? run : rem;
-                        const int rs = run < 5 ? run : 5;
+                        run = run < K ? run : K - 1;                         // (a K-mer inside the window would have been a max-mer)
+                        const int rs = run < LVL ? run : LVL;
                         if (rs >= kmin) {
-                            const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (16 - 2 * rs));
+                            const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (2 * K - 2 * rs));
                             atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
                         }
-                        if (run >= 6) {
+                        if (run >= K - 2) {
                             const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
                             if (slot < FRISK8_ORPH_CAP)
-                                orph[slot] = uint16_t(run == 7 ? (c16 >> 2) : (0x8000u | ((c16 >> 4) << 2)));
+                                orph[slot] = uint16_t(run == K - 1 ? (c16 >> 2) : (0x8000u | ((c16 >> 4) << 2)));
                         }
                     }
                 }
@@ -266,6 +273,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         for (int it = 0; it < ITS; ++it) tally((lowm >> (31 - it)) & 1u, uint32_t(acode >> (62 - 2 * it)) & 3u);
                     }
                 }
+                {   // the code of one max-mer of this window, any: positions that start none score it with weight 0, so that
+                    // every lane computes finite values and no term needs masking (which wave's wins does not matter)
+                    const unsigned long long have = __ballot(fullm != 0u);
+                    if (have) {
+                        const uint32_t mine = uint32_t(acode >> (64 - 2 * K - 2 * int(__clz(int(fullm | 1u))))) & (NK - 1u);
+                        const uint32_t pick = uint32_t(__builtin_amdgcn_readlane(int(mine), int(__ffsll((long long)have)) - 1));
+                        if (lane == 0) misc[M8_SAFE] = pick;
+                    }
+                }
                 if (lane == 0) {
                     if (cA) atomicAdd(&misc[M_UPA], cA);
                     if (cT) atomicAdd(&misc[M_UPT], cT);
@@ -278,10 +294,10 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             if (tid < FRISK8_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
 
             // ---- stage 2: C_5[q] = D_5[q] + (sum of the 64 order-8 counters below q); grand total for the overflow check
-            const uint32_t o5 = uint32_t(table_offset(kmin, 5));
+            const uint32_t o5 = uint32_t(table_offset(kmin, LVL));         // the small tables' top order: K-3
             {
                 uint32_t tot = 0;
-                for (uint32_t q5 = tid; q5 < 1024u; q5 += NT) {
+                for (uint32_t q5 = tid; q5 < NL; q5 += NT) {
                     uint32_t s = 0;
                     if (BITS == 8) {
 #pragma unroll
@@ -307,34 +323,54 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 if (lane == 0 && tot) atomicAdd(&misc[M8_TSUM], tot);
             }
             __syncthreads();
-            // orders 4..1 inside wave 0: lane l takes the 4-mers l + 64 i; 3-mers are sums over quads, 2-mers over rows of
-            // 16 lanes, 1-mers over the wave - no LDS round trip between the levels
-            if (tid < 64 && kmin <= 4) {
-                const uint32_t o4 = uint32_t(table_offset(kmin, 4));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t q4 = uint32_t(tid) + 64u * i;
-                    const uint2 ch = *reinterpret_cast<const uint2*>(small16 + o5 + 4 * q4);
-                    const uint32_t c4 = small16[o4 + q4] + (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
-                    small16[o4 + q4] = uint16_t(c4);
-                    if (kmin <= 3) {
-                        uint32_t qs = dpp_addu<0xB1>(c4);
-                        qs = dpp_addu<0x4E>(qs);                                             // the quad's sum, in all four lanes
-                        const uint32_t o3 = uint32_t(table_offset(kmin, 3));
-                        uint32_t c3 = 0;
-                        if ((tid & 3) == 0) { c3 = small16[o3 + (tid >> 2) + 16 * i] + qs; small16[o3 + (tid >> 2) + 16 * i] = uint16_t(c3); }
-                        if (kmin <= 2) {
-                            uint32_t rs = dpp_addu<0xB1>(c3);
-                            rs = dpp_addu<0x4E>(rs); rs = dpp_addu<0x141>(rs); rs = dpp_addu<0x140>(rs);   // the row's four C_3
-                            const uint32_t o2 = uint32_t(table_offset(kmin, 2));
-                            uint32_t c2 = 0;
-                            if ((tid & 15) == 0) { c2 = small16[o2 + (tid >> 4) + 4 * i] + rs; small16[o2 + (tid >> 4) + 4 * i] = uint16_t(c2); }
-                            if (kmin <= 1) {
-                                const uint32_t ws = __builtin_amdgcn_readlane(int(c2), 0) + __builtin_amdgcn_readlane(int(c2), 16) +
-                                                    __builtin_amdgcn_readlane(int(c2), 32) + __builtin_amdgcn_readlane(int(c2), 48);
-                                if (tid == 0) small16[i] = uint16_t(small16[i] + ws);
+            // the orders below: inside a wave, no LDS round trip between the levels.  LVL >= 4: lane l of wave i takes the 4-mer
+            // l + 64 i (its count comes from its four 5-mers, or is final already when LVL = 4); 3-mers are sums over quads,
+            // 2-mers over rows of 16 lanes, the 1-mer i over the wave; the four quarters of the 4-mer space are independent
+            // (one wave each; a workgroup of fewer waves loops).  LVL = 3: one wave, lane l = the 3-mer l.
+            if constexpr (LVL >= 4) {
+                if (tid < 256 && kmin <= 4 && (LVL == 5 || kmin <= 3)) {
+                    const uint32_t o4 = uint32_t(table_offset(kmin, 4));
+                    for (int i = tid >> 6; i < 4; i += (NT >= 256 ? 4 : NT / 64)) {
+                        const uint32_t q4 = uint32_t(tid & 63) + 64u * i;
+                        uint32_t c4 = small16[o4 + q4];
+                        if constexpr (LVL == 5) {
+                            const uint2 ch = *reinterpret_cast<const uint2*>(small16 + o5 + 4 * q4);
+                            c4 += (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
+                            small16[o4 + q4] = uint16_t(c4);
+                        }
+                        if (kmin <= 3) {
+                            uint32_t qs = dpp_addu<0xB1>(c4);
+                            qs = dpp_addu<0x4E>(qs);                                             // the quad's sum, in all four lanes
+                            const uint32_t o3 = uint32_t(table_offset(kmin, 3));
+                            uint32_t c3 = 0;
+                            if ((lane & 3) == 0) { c3 = small16[o3 + (lane >> 2) + 16 * i] + qs; small16[o3 + (lane >> 2) + 16 * i] = uint16_t(c3); }
+                            if (kmin <= 2) {
+                                uint32_t rs = dpp_addu<0xB1>(c3);
+                                rs = dpp_addu<0x4E>(rs); rs = dpp_addu<0x141>(rs); rs = dpp_addu<0x140>(rs);   // the row's four C_3
+                                const uint32_t o2 = uint32_t(table_offset(kmin, 2));
+                                uint32_t c2 = 0;
+                                if ((lane & 15) == 0) { c2 = small16[o2 + (lane >> 4) + 4 * i] + rs; small16[o2 + (lane >> 4) + 4 * i] = uint16_t(c2); }
+                                if (kmin <= 1) {
+                                    const uint32_t ws = __builtin_amdgcn_readlane(int(c2), 0) + __builtin_amdgcn_readlane(int(c2), 16) +
+                                                        __builtin_amdgcn_readlane(int(c2), 32) + __builtin_amdgcn_readlane(int(c2), 48);
+                                    if (lane == 0) small16[i] = uint16_t(small16[i] + ws);
+                                }
                             }
                         }
+                    }
+                }
+            } else {
+                if (tid < 64 && kmin <= 2) {
+                    const uint32_t c3 = small16[uint32_t(table_offset(kmin, 3)) + uint32_t(tid)];     // final already
+                    uint32_t qs = dpp_addu<0xB1>(c3);
+                    qs = dpp_addu<0x4E>(qs);                                                         // the four 3-mers of a 2-mer
+                    const uint32_t o2 = uint32_t(table_offset(kmin, 2));
+                    uint32_t c2 = 0;
+                    if ((tid & 3) == 0) { c2 = small16[o2 + (tid >> 2)] + qs; small16[o2 + (tid >> 2)] = uint16_t(c2); }
+                    if (kmin <= 1) {
+                        uint32_t rs = dpp_addu<0xB1>(c2);
+                        rs = dpp_addu<0x4E>(rs); rs = dpp_addu<0x141>(rs); rs = dpp_addu<0x140>(rs);   // the row's four C_2
+                        if ((tid & 15) == 0) small16[tid >> 4] = uint16_t(small16[tid >> 4] + rs);
                     }
                 }
             }
@@ -352,6 +388,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const uint32_t nvalid_top = uni(misc[M_NVALID]);
             const int n_orph = int(uni(misc[M_NORPH]));
             const bool wrapped = uni(misc[M8_TSUM]) != nvalid_top || n_orph > FRISK8_ORPH_CAP;
+            const uint32_t safe_code = uni(misc[M8_SAFE]);
 
             auto zero_own = [&]() {             // every max-mer position clears its dword (all reads are behind a barrier)
 #pragma unroll 4
@@ -392,7 +429,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             for (int k = 0; k < 4; ++k) {
                 if (k < n_orph) {
                     const uint32_t e = uni(uint32_t(orph[k]));
-                    o6[k] = (e >> 2) & 0xFFFu;
+                    o6[k] = (e >> 2) & (NK / 16u - 1u);
                     if (!(e & 0x8000u)) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) if (q == n7) o7[q] = e;
@@ -405,11 +442,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             struct Fetched { double Ig, A5; uint32_t W5, c8, w7; uint4 w6; };
             auto fetch = [&](uint32_t c16) __attribute__((always_inline)) -> Fetched {
                 Fetched f;
-                f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^8 always
+                f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^K always
                 if (BITS == 8) {        // the counter of code c is byte c of the table
                     f.c8 = t8b[c16];
-                    f.w7 = *reinterpret_cast<const uint32_t*>(t8b + (c16 & 0xFFFCu));
-                    f.w6 = *reinterpret_cast<const uint4*>(t8b + (c16 & 0xFFF0u));
+                    f.w7 = *reinterpret_cast<const uint32_t*>(t8b + (c16 & ~3u));
+                    f.w6 = *reinterpret_cast<const uint4*>(t8b + (c16 & ~15u));
                 } else {                // the four nibbles of the 7-mer c >> 2 are the 16 bits at byte 2 (c >> 2)
                     f.c8 = 0;
                     f.w7 = *reinterpret_cast<const uint16_t*>(t8b + ((c16 >> 2) << 1));
@@ -444,7 +481,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     for (int k = 4; k < n_orph; ++k) {
                         const uint32_t e = orph[k];
                         c7 += (q7 == e) ? 1u : 0u;
-                        c6 += (q6 == ((e >> 2) & 0xFFFu)) ? 1u : 0u;
+                        c6 += (q6 == ((e >> 2) & (NK / 16u - 1u))) ? 1u : 0u;
                     }
             };
             using orph2 = std::integral_constant<int, 2>;
@@ -452,11 +489,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             using orphN = std::integral_constant<int, 0>;
             // count of the x-mer c in this window (row metadata, RIP, debug dump)
             auto count = [&](int x, uint32_t c) -> uint32_t {
-                if (x <= 5) return small16[table_offset(kmin, x) + c];
+                if (x <= LVL) return small16[table_offset(kmin, x) + c];
                 uint32_t c8, c7, c6;
-                const uint32_t c16 = c << (2 * (8 - x));
+                const uint32_t c16 = c << (2 * (K - x));
                 top_counts(fetch(c16), c16, orphN{}, c8, c7, c6);
-                return x == 8 ? c8 : (x == 7 ? c7 : c6);
+                return x == K ? c8 : (x == K - 1 ? c7 : c6);
             };
 
             // ---- stage 3: window constants r_x = 4^x / D_x, D_x = (S-(x-1))*2 (L401-409), and the shared prefix tables
@@ -467,7 +504,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                                         __builtin_amdgcn_readlane(__double2loint(r_lane), x));
             };
             {
-                constexpr int LV = 5;
+                constexpr int LV = LVL;
                 double rx[LV + 1];
                 uint32_t ox[LV + 1], wm[LV + 1];
 #pragma unroll
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     wm[x] = on ? 0xFFFFFFFFu : 0u;
                 }
 #pragma unroll 2
-                for (uint32_t c = tid; c < 1024u; c += NT) {
+                for (uint32_t c = tid; c < NL; c += NT) {
                     uint32_t cx[LV + 1];
 #pragma unroll
                     for (int x = 1; x <= LV; ++x) cx[x] = small16[ox[x] + (c >> (2 * (LV - x)))];
@@ -498,18 +535,18 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 
             if (DEBUG && P.dbg_counts) {
                 uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
-                for (int x = kmin; x <= 8; ++x) {
+                for (int x = kmin; x <= K; ++x) {
                     const int64_t off = table_offset(kmin, x);
                     for (uint32_t c = tid; c < (1u << (2 * x)); c += NT) out[off + c] = count(x, c);
                 }
             }
             if (DEBUG && P.dbg_meta && tid == 0) {
                 P.dbg_meta[row * 3 + 0] = n;                                                   // totalLen
-                P.dbg_meta[row * 3 + 1] = (n >= 8 ? n - 8 + 1 : 0) - int64_t(nvalid_top);      // exMax (L344-345)
+                P.dbg_meta[row * 3 + 1] = (n >= K ? n - K + 1 : 0) - int64_t(nvalid_top);      // exMax (L344-345)
                 P.dbg_meta[row * 3 + 2] = nn;                                                  // nnTotal
             }
             if (nvalid_top == 0) status |= ROW_NO_MAXMER;
-            if (nvalid_top > 0 && S >= kmin - 1 && S <= 7) status |= ROW_ZERO_WEIGHT;          // zero divisor on the window side
+            if (nvalid_top > 0 && S >= kmin - 1 && S <= K - 1) status |= ROW_ZERO_WEIGHT;          // zero divisor on the window side
             status |= ROW_KEPT;
             if (tid == 0) {
                 P.gc[row] = __longlong_as_double((long long)((uint64_t(uint32_t(S)) << 32) | uint32_t(upG + upC)));
@@ -526,17 +563,16 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 
             // ---- stage 4: every max-mer position: window-side IVOM in closed form, genome side gathered, and the sums
             //      Sw = sum Iw/c8,  Sg = sum Ig/c8,  T = sum Iw ln(Iw/Ig)/c8  over POSITIONS (= sums over distinct max-mers)
-            const double r6 = r_of(6), r7 = r_of(7), r8 = r_of(8);
+            const double r6 = r_of(K - 2), r7 = r_of(K - 1), r8 = r_of(K);      // (named for K = 8: the three orders above the prefix)
             double sw = 0.0, sg = 0.0, stt = 0.0;
-            // a position that starts no max-mer must add exactly nothing: clearing the HIGH word of its term leaves a
-            // subnormal or zero, whatever garbage (NaN included) its lanes computed
-            auto only_on = [](bool on, double x) -> double { return __hiloint2double(on ? __double2hiint(x) : 0, __double2loint(x)); };
+            // A position that starts no max-mer scores `safe_code` (a real max-mer of this window: finite values) with weight
+            // 1/c8 replaced by 0: it adds exactly +0.0 to every sum, and no term needs a mask.
             auto score_one = [&](const Fetched& f, uint32_t c16, bool on, auto orph_c) __attribute__((always_inline)) {
                 uint32_t c8, c7, c6;
                 top_counts(f, c16, orph_c, c8, c7, c6);
-                double rc = rctab[c8 & 15u];                                 // 1/c8 (1.0 for the 19 in 20 max-mers seen once)
+                double rc = rctab[(on ? c8 : 0u) & 15u];                     // 1/c8 (1.0 for the 19 in 20 max-mers seen once); [0] = 0
                 if (BITS == 8 && __builtin_expect(__any(c8 >= 16u), 0)) {     // (wave-uniform, rare: low-complexity sequence)
-                    if (c8 >= 16u) {                                          // beyond the table: reciprocal + two Newton steps
+                    if (on && c8 >= 16u) {                                    // beyond the table: reciprocal + two Newton steps
                         const double dc = double(c8);
                         double r = __builtin_amdgcn_rcp(dc);
                         r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
@@ -544,33 +580,71 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         rc = r;
                     }
                 }
-                const uint32_t W = f.W5 + (c6 << 12) + (c7 << 14) + (c8 << 16);
+                const uint32_t W = f.W5 + (c6 << (2 * K - 4)) + (c7 << (2 * K - 2)) + (c8 << (2 * K));
                 // c^2 exactly, as integers (< 2^32), then 4^x / D_x times it
                 double A = __builtin_fma(double(__umul24(c6, c6)), r6, f.A5);
                 A = __builtin_fma(double(__umul24(c7, c7)), r7, A);
                 A = __builtin_fma(double(__umul24(c8, c8)), r8, A);
-                // Iw = A/W and Iw/Ig with ONE division: ratio = A / (W * Ig), Iw = ratio * Ig
-                const double ratio = div_exact(A, double(W) * f.Ig);
+                // Iw = A/W and Iw/Ig with ONE reciprocal: ratio = A / (W * Ig), Iw = ratio * Ig.  v_rcp_f64 (24.4 bits) + one
+                // Newton step = 2^-48.8: the ratio carries a relative error of ~2e-15 - the level of the log table's - instead
+                // of being the correctly rounded quotient (two more instructions)
+                const double den = double(W) * f.Ig;
+                double rr = __builtin_amdgcn_rcp(den);
+                rr = __builtin_fma(rr, __builtin_fma(-den, rr, 1.0), rr);
+                const double ratio = A * rr;
                 const double Iwr = (ratio * f.Ig) * rc;                      // this position's share of Iw
                 const double ln = log_tab_n<LOGN, LOGDEG>(ratio, logtab);
-                sw += only_on(on, Iwr);
-                sg += only_on(on, f.Ig * rc);
-                stt += only_on(on, Iwr * ln);
+                sw += Iwr;
+                sg += f.Ig * rc;
+                stt += Iwr * ln;
             };
             // the lane's codes and flags again, opaque to the optimiser: without this it keeps every position's pre-shifted
             // code variants of stage 1 alive across the whole window (60 registers) instead of re-deriving them here
             uint32_t ah = uint32_t(acode >> 32), al = uint32_t(acode), fm4 = fullm;
             asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
             const uint64_t acode4 = (uint64_t(ah) << 32) | al;
-            auto code4_at = [&](int it) -> uint32_t { return uint32_t(acode4 >> (48 - 2 * it)) & 0xFFFFu; };
-#ifndef FRISK8_S4_GROUP
-#define FRISK8_S4_GROUP 2
+            auto code4_at = [&](int it) -> uint32_t {          // the position's max-mer, or the stand-in where it starts none
+                return ((fm4 >> (31 - it)) & 1u) ? (uint32_t(acode4 >> (64 - 2 * K - 2 * it)) & (NK - 1u)) : safe_code;
+            };
+            // Shape of the scoring loop, measured per K (bench shard / C2 shape, M windows/s):
+            //   K = 8 (LDS allows 3 / 2 workgroups per CU): unrolled, groups of 2: 44.8 / 36.2; rolled, groups of 1: 43.2 / 35.6
+            //   K = 6, 7 (tables of 4 / 16 KiB: registers bound the occupancy): unrolled at 3 per CU spills (26 / 24); rolled,
+            //   groups of 1, needs 89..92 registers, so FOUR workgroups share a CU: 50.2 / 45.3 (16-bit form: 31.0 / 26.0)
+#ifdef FRISK8_S4_GROUP
+            constexpr int GR = FRISK8_S4_GROUP;
+#else
+            constexpr int GR = K == 8 ? 2 : 1;
+#endif
+#ifdef FRISK8_ROLLED
+            constexpr bool ROLLED = FRISK8_ROLLED != 0;
+#else
+            constexpr bool ROLLED = K < 8;
 #endif
             auto score_all = [&](auto orph_c) __attribute__((always_inline)) {
-                constexpr int GR = FRISK8_S4_GROUP;
                 // software pipeline, fully unrolled: the reads of group g+1 are issued before the arithmetic of group g.
                 // (A rolled loop - two groups per trip, ping-pong buffers - needs 86..129 registers and no scratch, but
                 // measured 4..6 % slower at three workgroups per CU; thread counts 320 / 384 / 512 per workgroup 18..60 %.)
+                // the rolled form: two groups per trip, ping-pong buffers (ITS is a multiple of 2 GR for GR = 1, 2)
+                if constexpr (ROLLED && ITS % (2 * GR) == 0) {
+                    Fetched bufA[GR], bufB[GR];
+#pragma unroll
+                    for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(k));
+#pragma unroll 1
+                    for (int g = 0; g < ITS; g += 2 * GR) {
+#pragma unroll
+                        for (int k = 0; k < GR; ++k) bufB[k] = fetch(code4_at(g + GR + k));
+#pragma unroll
+                        for (int k = 0; k < GR; ++k) score_one(bufA[k], code4_at(g + k), (fm4 >> (31 - (g + k))) & 1u, orph_c);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int gn = g + 2 * GR < ITS ? g + 2 * GR : 0;       // (the last trip fetches group 0 again, unused)
+#pragma unroll
+                        for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(gn + k));
+#pragma unroll
+                        for (int k = 0; k < GR; ++k) score_one(bufB[k], code4_at(g + GR + k), (fm4 >> (31 - (g + GR + k))) & 1u, orph_c);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    return;
+                }
                 Fetched buf[2][GR];
 #pragma unroll
                 for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k));

@@ -519,11 +519,11 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
         res = e.scan(5000, 1000, rip=True)
         stat = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
         sub = e.scan(5000, 1000, rip=True, c0=1234, c1=4321)                   # another range: another sample, other widths
-        few = e.scan(5000, 1000, rip=True, c0=700, c1=1000)                     # too few windows to sample: 8-bit bulk
+        few = e.scan(5000, 1000, rip=True, c0=700, c1=1000)                     # same batch and geometry: the first sample's choice holds
         stat_few = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
     assert stat[0] == expect_bulk, stat
     assert stat[1] > 50 and stat[2] > 5, stat                                  # both hand-over lists were used
-    assert stat_few[0] == 8 and stat_few[1] == 0, stat_few
+    assert stat_few[0] == expect_bulk, stat_few
     for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):        # same bits whichever form scored the window
         assert np.array_equal(getattr(sub, f), getattr(res, f)[1234:4321], equal_nan=True), f
         assert np.array_equal(getattr(few, f), getattr(res, f)[700:1000], equal_nan=True), f
