@@ -585,3 +585,52 @@ def test_window_tile_sharding_equals_one_gpu(tmp_path, w, inc, scaffolds_all, km
                 assert np.array_equal(cat, getattr(full, f), equal_nan=True), (world, f)
         with pytest.raises(Exception):
             e.scan(w + 1, inc)                                          # the tiles were cut for another geometry
+
+
+def test_staged_residency_and_packed_form():
+    """frisk_seq_stage / _stage_packed / _commit / _export_packed: a batch uploaded into the second slot while another is
+    resident and being scanned gives, once committed, exactly the results of a plain load - from ASCII (page-locked and
+    pageable sources) and from the 0.5 B/base packed arrays; the resident batch is untouched until the commit."""
+    seqs_a = synth_seqs([90_000, 12_345, 0, 7_000], 51, island_frac=0.2, n_frac=0.1, lower_frac=0.1)
+    seqs_b = synth_seqs([64_000, 33_333, 5_001], 52, island_frac=0.1, n_frac=0.05, lower_frac=0.2)
+
+    def run(e):
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        return e.profile_raw(), e.scan(5000, 1000, rip=True)
+
+    def same(x, y):
+        assert np.array_equal(x[0], y[0])
+        for f in ("seq_index", "start", "stop", "status", "kld", "gc", "pi", "si", "cri"):
+            assert np.array_equal(getattr(x[1], f), getattr(y[1], f), equal_nan=True), f
+
+    with make_engine(1, 8) as e:
+        e.load(seqs_a); ref_a = run(e)
+        e.load(seqs_b); ref_b = run(e)
+        # pageable sources: B resident, A staged; B's results must not move while A is in flight
+        e.stage(seqs_a)
+        same(run(e), ref_b)
+        e.commit()
+        assert e.seq_lens == [len(s) for s in seqs_a]
+        assert e.read_seq(1) == bytes(c if c in b"ACGTacgt" else ord("N") for c in seqs_a[1])
+        same(run(e), ref_a)
+        # page-locked sources (asynchronous copies), several rounds of ping-pong
+        pinned = []
+        for i, s in enumerate(seqs_b):
+            a = e.host_array("b%d" % i, max(len(s), 1))
+            a[:len(s)] = np.frombuffer(s, dtype=np.uint8)
+            pinned.append(a[:len(s)])
+        for _ in range(3):
+            e.stage(pinned); same(run(e), ref_a); e.commit(); same(run(e), ref_b)
+            e.stage(seqs_a); e.commit(); same(run(e), ref_a)
+        # the packed form: export B's arrays, stage them over A, commit with names
+        e.stage(pinned); e.commit()
+        codes, inv, low = e.export_packed()
+        assert codes.size == 2 * (e.padded_len // 32) and inv.size == low.size == e.padded_len // 32
+        e.load(seqs_a)
+        e.stage_packed(codes, inv, low, [len(s) for s in seqs_b])
+        same(run(e), ref_a)
+        e.commit(names=["x", "y", "z"])
+        same(run(e), ref_b)
+        assert e._lib.frisk_seq_name(e._ctx, 1) == b"y"
+        with pytest.raises(Exception):
+            e.commit()                                  # nothing staged
