@@ -373,7 +373,7 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
     if (!c) return FRISK_E_HIP;
     *out = c;       // returned even on failure so that frisk_last_error() can be read; caller destroys it
     if (kmin < 1 || kmin > kmax || kmax > FRISK_MAX_K)
-        return fail(c, FRISK_E_ARG, "word sizes must satisfy 1 <= kmin <= kmax <= 8");
+        return fail(c, FRISK_E_ARG, "word sizes must satisfy 1 <= kmin <= kmax <= 12");
     c->device = device;
     c->kmin = kmin;
     c->kmax = kmax;
@@ -761,6 +761,18 @@ static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1
     if (p0 < 0 || p1 > c->b().padded_len || p0 > p1) return fail(c, FRISK_E_ARG, "position range outside the batch");
     HIPC(c, hipSetDevice(c->device));
     c->profile_final = false;
+    if (c->kmax > 8) {          // 4^K counters do not fit a CU: one global atomic per position (profile_kernels.h)
+        const int64_t nw = p1 > p0 ? ((p1 + 31) >> 5) - (p0 >> 5) : 0;
+        HIPC(c, hipEventRecord(c->evp0, c->stream));
+        if (nw > 0)
+            profile_add_big_kernel<<<grid_for(nw, 256, c->num_cu * 8), 256, 0, c->stream>>>(
+                c->b().d_codes.p, c->b().d_inv.p, c->b().d_low.p, p0, p1, c->kmin, c->kmax, mask_host ? 1 : 0, int(c->nprof),
+                reinterpret_cast<unsigned long long*>(c->d_raw.p));
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipEventRecord(c->evp1, c->stream));
+        c->ms_pending[1] = true;
+        return FRISK_OK;
+    }
     // order-K table privatised in LDS (u32): split in two halves at K = 8 (256 KiB does not fit a CU)
     const int halves = (c->kmax == 8) ? 2 : 1;
     const size_t lds = (size_t(1) << (2 * c->kmax)) / size_t(halves) * 4;
@@ -974,7 +986,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     P.lv = shared_level(c->kmin, c->kmax);
     LdsLayout L = make_layout(c->kmin, c->kmax, P.orphan_cap, P.lv);
     if (L.total > 160 * 1024 && P.lv) { P.lv = 0; L = make_layout(c->kmin, c->kmax, P.orphan_cap, 0); }
-    if (c->plan_maxwin <= 65535 && L.total > 160 * 1024)
+    if (c->kmax <= 8 && c->plan_maxwin <= 65535 && L.total > 160 * 1024)
         return fail(c, FRISK_E_ARG, "window too long for the 160 KB LDS of one workgroup");
     const int wg_per_cu = std::max(1, std::min(2, int(160 * 1024 / L.total)));
     int grid = int(std::min<int64_t>(n, int64_t(c->num_cu) * wg_per_cu));
@@ -1006,8 +1018,9 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     const bool narrow = narrow8 || narrow7;
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
-    if (c->plan_maxwin > 65535) {
-        // windows beyond the 16-bit LDS counters: 32-bit tables of all orders in a global scratch slice per workgroup
+    if (c->plan_maxwin > 65535 || c->kmax > 8) {
+        // windows beyond the 16-bit LDS counters, and every window at K > 8: 32-bit tables of all orders in a global scratch
+        // slice per workgroup
         const int big_grid = int(std::min<int64_t>(n, c->num_cu));
         const int64_t stride = (c->nprof + 3) / 4 * 4;
         HIPC(c, c->d_big.reserve(size_t(big_grid) * size_t(stride)));
@@ -1131,7 +1144,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
 #endif
 #ifndef FRISK_STOP
-    if (c->plan_maxwin <= 65535 && n > 0) {     // the LDS kernels leave the rows' scalar tail to one thread per row
+    if (c->plan_maxwin <= 65535 && c->kmax <= 8 && n > 0) {     // the LDS kernels leave the rows' scalar tail to one thread per row
         finish_rows_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(n, c->o_status.p, c->o_kld.p, c->o_gc.p, c->o_sw.p,
                                                                             c->o_sg.p);
         HIPC(c, hipGetLastError());

@@ -14,7 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define FRISK_MAX_K 8
+#define FRISK_MAX_K 12             // orders above 8 take the global-memory paths (scan_big_kernel, profile_add_big_kernel)
 #define FRISK_PAD_BYTE 0
 
 struct ScafDesc {
@@ -58,6 +58,25 @@ __device__ inline uint32_t fetch_mask1(const uint32_t* __restrict__ mask, int64_
 __device__ inline uint32_t fetch_code2(const uint32_t* __restrict__ codes, int64_t g) {
     return (codes[g >> 4] >> (30 - 2 * int(g & 15))) & 3u;
 }
+
+// 24 bits = the 12 bases starting at padded position g (orders above 8)
+__device__ inline uint32_t fetch_codes24(const uint32_t* __restrict__ codes, int64_t g) {
+    const int64_t wi = g >> 4;
+    const int sh = int(g & 15) * 2;
+    const uint64_t cat = (uint64_t(codes[wi]) << 32) | codes[wi + 1];
+    return uint32_t(cat >> (40 - sh)) & 0xFFFFFFu;
+}
+
+// 16 mask bits for the 16 positions starting at g (position g = bit 15)
+__device__ inline uint32_t fetch_mask16(const uint32_t* __restrict__ mask, int64_t g) {
+    const int64_t wi = g >> 5;
+    const int sh = int(g & 31);
+    const uint64_t cat = (uint64_t(mask[wi]) << 32) | mask[wi + 1];
+    return uint32_t(cat >> (48 - sh)) & 0xFFFFu;
+}
+
+// number of leading clear bits of a 16-bit field (16 if the field is 0)
+__device__ inline int lead_clear16(uint32_t m16) { return m16 ? (__clz(int(m16)) - 16) : 16; }
 
 // number of leading clear bits of an 8-bit field (8 if the field is 0)
 __device__ inline int lead_clear8(uint32_t m8) { return m8 ? (__clz(int(m8)) - 24) : 8; }

@@ -166,6 +166,59 @@ __global__ __launch_bounds__(FRISK_PROF_NT) void profile_add_kernel(const uint32
     }
 }
 
+// The same counting for kmax > 8 (4^K 32-bit counters no longer fit a CU's LDS): every position's ONE update goes straight to
+// the global table of its order.  A lane owns one 32-position word of the bitmaps as above; 24-bit codes (12 bases).
+// ~20 ms per 400 Mb - the reference's -k is unbounded (L1197-1206) but its own cost grows with 4^K; this path is for
+// completeness, not speed.
+__global__ __launch_bounds__(256) void profile_add_big_kernel(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ inv,
+                                                               const uint32_t* __restrict__ low, int64_t p0, int64_t p1, int kmin,
+                                                               int kmax, int mask_host, int nprof,
+                                                               unsigned long long* __restrict__ raw) {
+    unsigned long long tot = 0, kpos = 0, nn = 0;
+    const int64_t w_first = p0 >> 5, w_end = (p1 + 31) >> 5;
+    auto topbits = [](int64_t k) -> uint32_t {
+        k = k < 0 ? 0 : (k > 32 ? 32 : k);
+        return uint32_t(0xFFFFFFFF00000000ull >> k);
+    };
+    for (int64_t wq = w_first + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; wq < w_end; wq += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t base = wq << 5;
+        const uint32_t i0 = inv[wq], i1 = inv[wq + 1], l0 = low[wq], l1 = low[wq + 1];
+        const uint32_t c0 = codes[2 * wq], c1 = codes[2 * wq + 1], c2 = codes[2 * wq + 2];
+        const uint32_t inr = topbits(p1 - base) & ~topbits(p0 - base);
+        const uint32_t e0 = i0 | (mask_host ? l0 : 0u), e1 = i1 | (mask_host ? l1 : 0u);
+        const uint64_t V = ~((uint64_t(e0) << 32) | e1);                    // countable bases; position base+j at bit 63-j
+        const uint64_t lo64 = (uint64_t(c0) << 32) | c1, hi64 = (uint64_t(c1) << 32) | c2;
+        uint32_t todo = uint32_t(V >> 32) & inr;
+        while (todo) {
+            const int j = __clz(int(todo));
+            todo &= ~(0x80000000u >> j);
+            int run = __clzll((long long)(~(V << j)));                      // countable bases from here on (<= 32 visible)
+            run = run < kmax ? run : kmax;
+            if (run >= kmin) {
+                const uint32_t c24 = uint32_t((j < 16 ? lo64 : hi64) >> (40 - 2 * (j & 15))) & 0xFFFFFFu;
+                atomicAdd(&raw[table_offset(kmin, run) + (c24 >> (24 - 2 * run))], 1ull);
+            }
+        }
+        const uint64_t NP = ~((uint64_t(i0 & l0) << 32) | (i1 & l1));       // not a PAD
+        uint64_t G = NP;                                                    // a K-mer can start here (L329): no PAD in reach
+        for (int s = 1; s < kmax; ++s) G &= NP << s;
+        const uint32_t real = uint32_t(NP >> 32) & inr;
+        tot += __popc(real);
+        nn += __popc(real & (i0 | l0));                                     // not an uppercase A/T/G/C (countN, L106-118)
+        kpos += __popc(uint32_t(G >> 32) & inr);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        tot += __shfl_down(tot, o);
+        kpos += __shfl_down(kpos, o);
+        nn += __shfl_down(nn, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (tot) atomicAdd(&raw[nprof + 0], tot);
+        if (kpos) atomicAdd(&raw[nprof + 1], kpos);
+        if (nn) atomicAdd(&raw[nprof + 2], nn);
+    }
+}
+
 // C_x[q] = D_x[q] + sum_b C_{x+1}[4q+b], in place on a copy of the D tables; one launch per order,
 // from K-1 down to kmin (4^x threads each).
 __global__ __launch_bounds__(256) void marginalize_kernel(int64_t* __restrict__ cnt, int kmin, int x) {

@@ -1,4 +1,5 @@
-// frisk_amd - windows longer than 65 535 bases (any length up to 2^31-1): the histogram of a window does not fit
+// frisk_amd - windows longer than 65 535 bases (any length up to 2^31-1), and every window when kmax > 8 (the reference's -k
+// is unbounded, L1197-1206; this path serves orders up to FRISK_MAX_K = 12): the histogram of a window does not fit
 // 16-bit LDS counters any more, so a workgroup keeps 32-bit tables of ALL orders in its own slice of a global
 // scratch buffer (L2-resident: 350 KB per workgroup at k = 1..8).  Same algorithm as scan_kernel.h -
 //   one update per position at the order of its longest valid word, marginalisation C_x = D_x + sum children,
@@ -64,16 +65,16 @@ __global__ __launch_bounds__(FRISK_BIG_NT) void scan_big_kernel(const ScanParams
             const int64_t jj = base + tid;
             const bool act = jj < n;
             const int64_t g = g0 + (act ? jj : 0);
-            const uint32_t c16 = fetch_codes16(P.codes, g);
-            const uint32_t inv8 = fetch_mask8(P.inv, g);
+            const uint32_t c24 = fetch_codes24(P.codes, g);                 // 12 bases: orders up to FRISK_MAX_K
+            const uint32_t inv16 = fetch_mask16(P.inv, g);
             const uint32_t low1 = fetch_mask1(P.low, g);
-            int run = lead_clear8(inv8);                                    // window words are upper-cased: L334-335
+            int run = lead_clear16(inv16);                                  // window words are upper-cased: L334-335
             const int64_t rem = n - jj;
             run = run < rem ? run : int(rem);
             run = run < kmax ? run : kmax;
-            if (act && run >= kmin) atomicAdd(&cnt[table_offset(kmin, run) + (c16 >> (16 - 2 * run))], 1u);
-            const bool up = act && !((inv8 >> 7) | low1);
-            const uint32_t c2 = c16 >> 14;
+            if (act && run >= kmin) atomicAdd(&cnt[table_offset(kmin, run) + (c24 >> (24 - 2 * run))], 1u);
+            const bool up = act && !((inv16 >> 15) | low1);
+            const uint32_t c2 = c24 >> 22;
             cA += __popcll(__ballot(up && c2 == 0));
             cT += __popcll(__ballot(up && c2 == 1));
             cG += __popcll(__ballot(up && c2 == 2));

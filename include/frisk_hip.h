@@ -50,8 +50,9 @@ enum {
 
 const char* frisk_version(void);
 
-/* Library limits for (kmin,kmax,window length); 0 = unsupported.  kmax <= 8; windows up to 65535 bases run in LDS,
- * longer ones (up to 2^31-1) on a slower path with 32-bit tables in global memory. */
+/* Library limits for (kmin,kmax,window length); 0 = unsupported.  kmax <= 12 (the reference's -k is unbounded, L1197-1206,
+ * but its own cost grows with 4^K); kmax <= 8 and windows up to 65535 bases run in LDS, everything else (windows up to
+ * 2^31-1 bases, kmax 9..12) on a slower path with 32-bit tables in global memory. */
 int frisk_supported(int kmin, int kmax, int64_t max_window);
 
 /* Context: device ordinal, word sizes -m/-k (L1197-1206). */

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, n) is not None
     assert b"gfx950" in lib.frisk_version()
     assert lib.frisk_supported(1, 8, 5000) == 1
-    assert lib.frisk_supported(1, 9, 5000) == 0 and lib.frisk_supported(3, 2, 5000) == 0
+    assert lib.frisk_supported(1, 12, 5000) == 1 and lib.frisk_supported(1, 13, 5000) == 0 and lib.frisk_supported(3, 2, 5000) == 0
     assert lib.frisk_supported(1, 8, 70000) == 1 and lib.frisk_supported(1, 8, 2 ** 31) == 0 and lib.frisk_supported(1, 8, 0) == 0
 
 

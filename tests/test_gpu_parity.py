@@ -211,7 +211,7 @@ def test_error_paths_and_edge_batches():
         with pytest.raises(_ffi.FriskHipError):
             e.profile_add(pos_begin=5, pos_end=10 ** 9)
     with pytest.raises(_ffi.FriskHipError):
-        make_engine(1, 9)
+        make_engine(1, 13)
     with pytest.raises(_ffi.FriskHipError):
         make_engine(0, 3)
     with make_engine(1, 8) as e:
@@ -634,3 +634,41 @@ def test_staged_residency_and_packed_form():
         assert e._lib.frisk_seq_name(e._ctx, 1) == b"y"
         with pytest.raises(Exception):
             e.commit()                                  # nothing staged
+
+
+@pytest.mark.parametrize("kmin,kmax,w,inc,rip", [(1, 9, 3000, 1000, True), (2, 10, 5000, 2500, True), (9, 9, 2000, 1000, False),
+                                                 (7, 11, 4000, 4000, False)])
+def test_orders_above_eight_against_c_oracle(kmin, kmax, w, inc, rip):
+    """-k above 8 (the reference's -k is unbounded, L1197-1206): the global-memory paths - profile with one global atomic
+    per position, window tables of all orders in a scratch slice per workgroup - against the compiled oracle: profile
+    bit-exact, rows bit-exact on integers / GC / RIP, KLD to 1e-11, count tables of a few windows."""
+    from oracle import frisk_oracle_c as OC
+    seqs = synth_seqs([60_000, 9_000, 20_011, 300], 61, island_frac=0.2, n_frac=0.06, lower_frac=0.05)
+    with make_engine(kmin, kmax) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        res = e.scan(w, inc, rip=rip and kmin <= 2)
+        dbg = e.scan(w, inc, c0=3, c1=6, debug=True)
+        half = e.padded_len // 2 // 32 * 32
+        e.profile_reset(); e.profile_add(pos_begin=0, pos_end=half); e.profile_add(pos_begin=half, pos_end=e.padded_len)
+        e.profile_finalize()
+        sym2 = e.profile_get()[0]
+    osym, ometa = OC.genome_profile(seqs, kmin, kmax)
+    assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+    assert np.array_equal(sym2, osym)                                           # linear over position ranges here too
+    ig = OC.genome_ivom(osym, ometa, kmin, kmax)
+    exp = OC.scan(seqs, ig, kmin, kmax, w, inc, rip=rip and kmin <= 2)
+    exp_dbg = OC.scan(seqs, ig, kmin, kmax, w, inc, cand=(3, 6), debug=True)           # (the count tables are 4^K wide: three rows)
+    k = np.nonzero(res.kept)[0]
+    assert len(k) == len(exp["kld"]) and len(k) >= 8
+    assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"])
+    assert np.array_equal(res.gc[k], exp["gc"])
+    if rip and kmin <= 2:
+        for col in ("pi", "si", "cri"):
+            assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
+    assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
+    kd = np.nonzero(dbg.kept)[0]
+    assert len(kd) == len(exp_dbg["kld"]) >= 1
+    assert np.array_equal(dbg.counts[kd].astype(np.int64), exp_dbg["counts"].astype(np.int64))
+    assert np.array_equal(dbg.meta[kd], exp_dbg["meta"])
