@@ -232,9 +232,9 @@ void plan_scaffold(int64_t size, int32_t w, int32_t inc, bool all, int64_t& ncan
     }
 }
 
-template <int NT, bool K8, int ITS, bool DEBUG, bool QUART = false>
+template <int NT, bool K8, int ITS, bool DEBUG>
 hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st) {
-    auto kern = scan_kernel<NT, K8, ITS, DEBUG, QUART>;
+    auto kern = scan_kernel<NT, K8, ITS, DEBUG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(lds));
     if (e != hipSuccess) return e;
@@ -1000,19 +1000,13 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     const int64_t need = (c->plan_maxwin + 511) / 512;
     const int its = need <= 4 ? 4 : need <= 10 ? 10 : need <= 16 ? 16 : 0;
 
-    // quarter-table form of the K = 8 fast paths (two workgroups per CU)
-    P.list_cap = int32_t((c->plan_maxwin + 7) / 8 * 8);
-    const LdsLayout Lq = make_layout(c->kmin, c->kmax, P.orphan_cap, P.lv, true, P.list_cap);
-    // (since the per-row tail and the wave reductions left the critical path, one 512-thread workgroup per CU is the faster
-    //  form at K = 8 again - 25.0 vs 23.6 M windows/s on the bench shard; FRISK_K8_QUART=1 selects the two-workgroup form)
-    const bool quart = k8 && c->plan_maxwin <= 5120 && Lq.total <= 80 * 1024 && tune_env("FRISK_K8_QUART");
     const bool force_one = tune_env("FRISK_ONE_WG") != nullptr;      // tuning knob: never two workgroups per CU
     // narrow-counter form (scan8_kernel.h): K = 8, kmin <= 5 (shared prefix level), windows of at most 256 x 20 bases.
     // width 0 = adaptive (the default), 4 / 8 = fixed, anything else = off (scan_kernel.h's 16-bit form for everything)
     int width = FRISK_K8_WIDTH;
     if (const char* ev = tune_env("FRISK_K8_BITS")) width = std::atoi(ev);
     // (decided by -w alone: rescued small scaffolds beyond the kernel's reach are handed on per window, see scan8_kernel.h)
-    const bool narrow8 = k8 && c->kmin <= 5 && w <= 5120 && c->plan_maxwin <= 65535 && (width == 0 || width == 4 || width == 8) && !quart;
+    const bool narrow8 = k8 && c->kmin <= 5 && w <= 5120 && c->plan_maxwin <= 65535 && (width == 0 || width == 4 || width == 8);
     // K = 6, 7: the same kernel with 8-bit counters (a K-mer must occur 256 times in a window to wrap one)
     const bool narrow7 = (c->kmax == 6 || c->kmax == 7) && c->kmin <= c->kmax - 3 && w <= 5120 && c->plan_maxwin <= 65535 && width != 16;
     const bool narrow = narrow8 || narrow7;
@@ -1095,14 +1089,6 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
             else if (its == 16) FRISK_LAUNCH(512, false, 16, false);
             else FRISK_LAUNCH(1024, false, 0, false);
         }
-    } else if (k8 && !debug && quart) {
-        // K = 8 with TWO independent 256-thread workgroups per CU: the order-8 table serves one leading base at a time
-        // (32 KiB), the window's max-mers are bucketed by leading base and handled in four passes (scan_kernel.h, QUART)
-        grid = int(std::min<int64_t>(n, int64_t(c->num_cu) * 2));
-        if (grid >= 8) grid &= ~7;
-        P.chunk = int32_t(std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(grid) * 8), 8)));
-        if (c->plan_maxwin <= 2048) e = launch_scan<256, true, 8, false, true>(P, grid, Lq.total, c->stream);
-        else e = launch_scan<256, true, 20, false, true>(P, grid, Lq.total, c->stream);
     } else if (k8) {
         if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
         else if (its == 4) FRISK_LAUNCH(512, true, 4, false);

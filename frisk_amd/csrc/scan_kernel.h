@@ -58,7 +58,6 @@ struct ScanParams {
     int32_t chunk;            // consecutive candidates handed to a workgroup at a time
     int32_t orphan_cap;       // capacity of the orphan list (entries)
     int32_t lv;               // shared_level(), or 0 when the prefix tables do not fit beside a long window's orphan list
-    int32_t list_cap;         // entries of the bucketed max-mer list (quarter-table kernels; >= longest window)
     int32_t nprof;            // profile length (debug dump stride)
     // outputs, indexed by (candidate - c0)
     int32_t* seq_index;
@@ -134,8 +133,7 @@ struct LdsLayout {
     uint32_t rtab;      // f64[16]: 4^x / ((S-(x-1))*2) per order x (window constants)
     uint32_t logtab;    // f64[2*FRISK_LOGTAB_N]: {1/c_i, ln c_i}, written once per workgroup
     uint32_t misc;      // 2 x 16 u32 counters (double-buffered by window parity) + reduction scratch
-    uint32_t list;      // u16[list_cap]: the window's max-mer codes bucketed by leading base (quarter-table kernels only)
-    uint32_t t8_bytes;  // 128 KiB, or 32 KiB when the order-8 table holds ONE leading base at a time
+    uint32_t t8_bytes;  // 128 KiB at K = 8
     uint32_t total;
 };
 
@@ -146,14 +144,13 @@ __host__ __device__ inline int shared_level(int kmin, int kmax) { return (kmin <
 #define FRISK_LOGTAB_N 128
 #define FRISK_MISC_BYTES (2 * FRISK_MISC_SLOTS * 4 + 16 * 6 * 8)       // counters x2, scratch (16 waves x 3 x 128 bit)
 
-__host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap, int lv, bool quart = false,
-                                                 int list_cap = 0) {
+__host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_cap, int lv) {
     LdsLayout L;
     const bool k8 = (kmax == 8);
     const int ks = k8 ? 6 : kmax;
     uint32_t o = 0;
     L.t8 = o;
-    L.t8_bytes = k8 ? (quart ? FRISK_T8_BYTES / 4 : FRISK_T8_BYTES) : 0;
+    L.t8_bytes = k8 ? FRISK_T8_BYTES : 0;
     o += L.t8_bytes;
     L.small = o;
     int64_t bins = (ks >= kmin) ? table_offset(kmin, ks + 1) : 0;
@@ -171,35 +168,22 @@ __host__ __device__ inline LdsLayout make_layout(int kmin, int kmax, int orphan_
     o += FRISK_LOGTAB_N * 16;
     L.misc = o;
     o += FRISK_MISC_BYTES;
-    L.list = o;
-    if (quart) o += uint32_t(list_cap * 2 + 15) / 16 * 16;
     L.total = (o + 15) / 16 * 16;
     return L;
 }
 
 // misc counter slots
-enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS, M_CLS = 8 /* ..11: max-mers per leading base */, M_OVF = 12 };
+enum { M_UPA = 0, M_UPT, M_UPG, M_UPC, M_NORPH, M_NVALID, M_FLAGS };
 
-// MODE = how the order-8 table is held (K = 8):
-//   0  all 4^8 bins, 16-bit (128 KiB)                                   - one workgroup per CU
-//   1  the bins of ONE leading base at a time, 16-bit (32 KiB, index = low 14 bits of the code)
-//   2  the bins of one leading BIT (two leading bases) at a time, 8-bit (32 KiB, index = low 15 bits) - valid while no
-//      max-mer occurs more than 255 times in the window; the kernel detects the overflow and redoes the pass in mode 1
-template <bool K8, int MODE = 0>
+template <bool K8>
 struct WinTables {
-    static constexpr uint32_t M8 = MODE == 0 ? 0xFFFFu : (MODE == 1 ? 0x3FFFu : 0x7FFFu), M7 = M8 >> 2;
+    static constexpr uint32_t M7 = 0x3FFFu;
     const uint16_t* t8_16;
     const uint16_t* small16;
     const uint16_t* orph;
     int n_orph;
     uint32_t o0, o1, o2, o3;     // the first four orphan 7-mers (0xFFFFFFFF = none), wave-uniform
     int kmin;
-
-    template <int M2>
-    __device__ inline void same_window_as(const WinTables<K8, M2>& o) {
-        t8_16 = o.t8_16; small16 = o.small16; orph = o.orph; n_orph = o.n_orph;
-        o0 = o.o0; o1 = o.o1; o2 = o.o2; o3 = o.o3; kmin = o.kmin;
-    }
 
     // occurrences of the 7-mer `c` in the orphan list: a window has one orphan (its tail) plus one per invalid run -
     // almost always <= 4
@@ -214,16 +198,10 @@ struct WinTables {
     // the max-mer's own count and the sum over the four children of its 7-mer prefix, from ONE aligned read
     __device__ inline void top(uint32_t code, uint32_t& c8, uint32_t& children) const {
         const uint32_t q7 = (code >> 2) & M7;
-        if (MODE == 2) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(t8_16) + 4 * q7);
-            c8 = (w >> ((code & 3u) * 8)) & 0xFFu;
-            children = __builtin_amdgcn_sad_u8(w, 0u, 0u);                   // sum of the four bytes
-        } else {
-            const uint2 ch = *reinterpret_cast<const uint2*>(t8_16 + 4 * q7);
-            const uint64_t both = (uint64_t(ch.y) << 32) | ch.x;
-            c8 = uint32_t(both >> ((code & 3u) * 16)) & 0xFFFFu;
-            children = (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
-        }
+        const uint2 ch = *reinterpret_cast<const uint2*>(t8_16 + 4 * q7);
+        const uint64_t both = (uint64_t(ch.y) << 32) | ch.x;
+        c8 = uint32_t(both >> ((code & 3u) * 16)) & 0xFFFFu;
+        children = (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
     }
 
     // count of the x-mer `c` in the current window.  ORPH = what the caller knows about the window's orphan list:
@@ -389,12 +367,8 @@ __device__ inline void block_sum3(ExactSum& a, ExactSum& b, ExactSum& c, double*
 // ITS > 0: the window has at most ITS*NT positions; per-position loops are fully unrolled and the per-position
 //          codes and IVOM values stay in registers between the passes.
 // ITS == 0: any length up to 65535; runtime loops, values recomputed in the last pass.
-// QUART (K = 8, two 256-thread workgroups per CU): the order-8 table is 32 KiB and serves one leading base at a time;
-//          the window's max-mer codes are bucketed by leading base into an LDS list and counted / scored / re-zeroed in
-//          four passes with full lanes.
-template <int NT, bool K8, int ITS, bool DEBUG, bool QUART = false>
+template <int NT, bool K8, int ITS, bool DEBUG>
 __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const ScanParams P) {
-    static_assert(!QUART || (K8 && ITS > 0 && !DEBUG), "the quarter-table form exists for the K = 8 fast paths only");
     constexpr int NW = NT / 64;
     constexpr int NREG = ITS > 0 ? ITS : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -402,8 +376,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     const int lane = tid & 63;
     const int kmin = P.kmin;
     const int kmax = K8 ? 8 : P.kmax;                   // compile-time at K = 8: the order loops unroll
-    const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap, P.lv, QUART, P.list_cap);
-    uint16_t* qlist = reinterpret_cast<uint16_t*>(lds + L.list);
+    const LdsLayout L = make_layout(kmin, kmax, P.orphan_cap, P.lv);
     uint32_t* t8 = reinterpret_cast<uint32_t*>(lds + L.t8);
     uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L.small);
     uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L.small);
@@ -499,8 +472,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             // (done before the N filter is known: 93 % of windows pass it, the others are cleaned up after stage 2)
             unsigned long long repmask = 0;
             uint32_t c16v[NREG];
-            unsigned long long q_off = 0;       // QUART: four 16-bit fields - where this lane's next max-mer of each leading base goes
-            uint32_t q_fullm = 0;               // QUART: the lane's positions that start a max-mer
             const bool tally_by_ballot = (kmin != 1);
             {
                 uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
@@ -596,10 +567,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                                     const uint32_t b = off_full + (c16 >> 4);
                                     atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
                                 }
-                                if constexpr (!QUART) {
-                                    const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
-                                    if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
-                                }
+                                const uint32_t old = atomicAdd(&t8[c16 >> 1], 1u << ((c16 & 1u) * 16));
+                                if (((old >> ((c16 & 1u) * 16)) & 0xFFFFu) == 0) repmask |= 1ull << it;
                             } else {
                                 const uint32_t b = off_full + (c16 >> sh_full);
                                 const uint32_t old = atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
@@ -614,31 +583,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     const uint32_t ntop = __popc(fullm);
 #pragma unroll
                     for (int b = 0; (1 << b) <= ITS; ++b) nvalid += uint32_t(__popcll(__ballot((ntop >> b) & 1u))) << b;
-                    if constexpr (QUART) {
-                        // bucket bookkeeping: the lane's max-mers per leading base (four 16-bit fields), an inclusive scan over
-                        // the wave, ONE atomic per wave and leading base for the wave's share of the window's totals
-                        unsigned long long cnt4 = 0;
-#pragma unroll
-                        for (int it = 0; it < ITS; ++it)
-                            if (fullm & (0x80000000u >> it)) cnt4 += 1ull << (16 * (c16v[it] >> 14));
-                        unsigned long long inc4 = cnt4;
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const unsigned long long up = __shfl_up(inc4, o);
-                            if (lane >= o) inc4 += up;
-                        }
-                        const unsigned long long wave4 = __shfl(inc4, 63);
-                        unsigned long long base4 = 0;
-                        if (lane == 0) {
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const uint32_t t = uint32_t(wave4 >> (16 * b)) & 0xFFFFu;
-                                if (t) base4 |= (unsigned long long)(atomicAdd(&misc[M_CLS + b], t)) << (16 * b);
-                            }
-                        }
-                        q_off = __shfl(base4, 0) + inc4 - cnt4;
-                        q_fullm = fullm;
-                    }
                     if (tally_by_ballot) {          // kmin > 1: no order-1 table to read the composition from
                         const uint32_t upm = actm & vld & ~alow;
 #pragma unroll
@@ -683,33 +627,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
             __syncthreads();
             STAMP(2)
             if (tid < FRISK_MISC_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
-            uint32_t q_tot[4] = {0, 0, 0, 0}, q_start[4] = {0, 0, 0, 0};   // QUART: the four buckets of the list
-            if constexpr (QUART) {
-                uint32_t run = 0;
-                unsigned long long start4 = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    q_tot[b] = __builtin_amdgcn_readfirstlane(misc[M_CLS + b]);
-                    q_start[b] = run;
-                    start4 |= (unsigned long long)run << (16 * b);
-                    run += q_tot[b];
-                }
-                unsigned long long off4 = q_off + start4;
-#pragma unroll
-                for (int it = 0; it < ITS; ++it) {
-                    if (q_fullm & (0x80000000u >> it)) {
-                        const uint32_t cls = c16v[it] >> 14;
-                        qlist[uint32_t(off4 >> (16 * cls)) & 0xFFFFu] = uint16_t(c16v[it]);
-                        off4 += 1ull << (16 * cls);
-                    }
-                }
-            }
             auto code16_at = [&](int it) -> uint32_t {
                 if (ITS > 0) return c16v[it];
                 return fetch_codes16(P.codes, g0 + tid + int64_t(it) * NT);
             };
             auto zero_own_bins = [&]() {        // representatives zero their max-mer bin (K8; the small tables are
-                if (K8 && !QUART) {             // cleared wholesale; the quarter-table passes re-zero as they go)
+                if (K8) {                       // cleared wholesale)
 #pragma unroll
                     for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it)
                         if ((repmask >> it) & 1ull) reinterpret_cast<uint16_t*>(t8)[code16_at(it)] = 0;
@@ -836,7 +759,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
 
             STOP_AFTER(2, small16[tid & 3] + nvalid_top)
 
-            WinTables<K8, (QUART ? 1 : 0)> T;
+            WinTables<K8> T;
             T.t8_16 = reinterpret_cast<const uint16_t*>(t8);
             T.small16 = small16;
             T.orph = orph; T.n_orph = n_orph;
@@ -1035,77 +958,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                     else body(orphN{}, std::false_type{});
                 }
             };
-            if constexpr (QUART) {
-                // Two passes, one per leading BIT, over 8-bit counters (32 KiB hold half of the k-mer space): count the two
-                // buckets into the table (electing representatives), score them with full lanes, re-zero the bins.  Thread t
-                // takes entries t, t+NT, ... of the pass in all three loops, so its representative flags stay in a register.
-                // A max-mer that occurs more than 255 times overflows its byte: the count loop sees it (old value 255), the
-                // pass is abandoned and redone bucket by bucket with 16-bit counters.  (Counting and re-zeroing from the lanes'
-                // own registers instead of the list was measured: half-empty atomics, +9 %.)
-                uint16_t* t8h = reinterpret_cast<uint16_t*>(t8);
-                uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
-                WinTables<K8, 2> T8;
-                T8.same_window_as(T);
-                auto pass16 = [&](int b) {                                      // one leading base, 16-bit counters
-                    const uint32_t nb = q_tot[b];
-                    const uint16_t* lst = qlist + q_start[b];
-                    uint32_t reps = 0;
-                    int k = 0;
-                    for (uint32_t e = tid; e < nb; e += NT, ++k) {
-                        const uint32_t idx = uint32_t(lst[e]) & 0x3FFFu;
-                        const uint32_t old = atomicAdd(&t8[idx >> 1], 1u << ((idx & 1u) * 16));
-                        if (((old >> ((idx & 1u) * 16)) & 0xFFFFu) == 0) reps |= 1u << k;
-                    }
-                    __syncthreads();
-                    with_variant([&](auto plain_c, auto lv_c) {
-                        int kk = 0;
-                        for (uint32_t e = tid; e < nb; e += NT, ++kk) score_one(T, uint32_t(lst[e]), (reps >> kk) & 1u, plain_c, lv_c);
-                    });
-                    __syncthreads();
-                    k = 0;
-                    for (uint32_t e = tid; e < nb; e += NT, ++k)
-                        if ((reps >> k) & 1u) t8h[uint32_t(lst[e]) & 0x3FFFu] = 0;
-                    __syncthreads();
-                };
-#pragma nounroll
-                for (int p = 0; p < 2; ++p) {
-                    const uint32_t nb = q_tot[2 * p] + q_tot[2 * p + 1];       // the two buckets are neighbours in the list
-                    const uint16_t* mine = qlist + q_start[2 * p];
-                    unsigned long long reps = 0;                                // <= 2 * ITS <= 40 entries per thread
-                    bool ovf = false;
-                    int k = 0;
-                    for (uint32_t e = tid; e < nb; e += NT, ++k) {
-                        const uint32_t idx = uint32_t(mine[e]) & 0x7FFFu;
-                        const uint32_t sh = (idx & 3u) * 8;
-                        const uint32_t old = (atomicAdd(&t8[idx >> 2], 1u << sh) >> sh) & 0xFFu;
-                        if (old == 0) reps |= 1ull << k;
-                        ovf |= (old == 255u);
-                    }
-#ifdef FRISK_Q_FORCE16      // experiment: always take the 16-bit four-pass route
-                    ovf = true;
-#endif
-                    if (ovf) misc[M_OVF] = 1u;
-                    __syncthreads();
-                    if (misc[M_OVF]) {                                          // (uniform) rare: low-complexity windows
-                        __syncthreads();                                        // everybody has seen the flag
-                        for (int i = tid; i < int(L.t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
-                        if (tid == 0) misc[M_OVF] = 0u;
-                        __syncthreads();
-                        pass16(2 * p);
-                        pass16(2 * p + 1);
-                    } else {
-                        with_variant([&](auto plain_c, auto lv_c) {
-                            int kk = 0;
-                            for (uint32_t e = tid; e < nb; e += NT, ++kk) score_one(T8, uint32_t(mine[e]), (reps >> kk) & 1ull, plain_c, lv_c);
-                        });
-                        __syncthreads();
-                        k = 0;
-                        for (uint32_t e = tid; e < nb; e += NT, ++k)
-                            if ((reps >> k) & 1ull) t8b[uint32_t(mine[e]) & 0x7FFFu] = 0;
-                        if (p == 0) __syncthreads();        // (after the last pass the block sum's barrier does it)
-                    }
-                }
-            } else {
                 with_variant([&](auto plain_c, auto lv_c) {
 #pragma unroll
                     for (int it = 0; ITS > 0 ? it < ITS : it * NT < n; ++it) {
@@ -1122,7 +974,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
                         if ((it % FRISK_S4_GROUP) == FRISK_S4_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 });
-            }
             STAMP(6)
             exact_end(accw); exact_end(accg); exact_end(acct);
 #ifdef FRISK_STOP

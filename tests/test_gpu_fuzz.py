@@ -41,9 +41,7 @@ def _random_case(rng):
 
 
 @pytest.mark.parametrize("block", range(16))
-def test_random_cases_against_c_oracle(block, monkeypatch):
-    if block >= 12:                     # the opt-in quarter-table form of the K = 8 kernel (two workgroups per CU)
-        monkeypatch.setenv("FRISK_K8_QUART", "1")
+def test_random_cases_against_c_oracle(block):
     rng = np.random.default_rng(1000 + block)
     checked = 0
     for case_no in range(25):
