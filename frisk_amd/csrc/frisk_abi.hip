@@ -242,18 +242,23 @@ hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st
     return hipGetLastError();
 }
 
-template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
+template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG, int ROLE = 0>
 hipError_t launch_scan8(const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
     constexpr int wg_per_cu = WPS * 256 / NT;
     static_assert(Lds8<KMAX, BITS, LOGN, NT>::total * wg_per_cu <= 160 * 1024, "the workgroups meant to share a CU must fit its LDS");
     int grid = int(std::max<int64_t>(1, std::min<int64_t>(work_items, int64_t(num_cu) * wg_per_cu)));
     if (grid >= 8) grid &= ~7;
-    scan8_kernel<KMAX, NT, ITS, BITS, LOGN, WPS, DEBUG><<<grid, NT, 0, st>>>(P);      // LDS is static (Lds8)
+    scan8_kernel<KMAX, NT, ITS, BITS, LOGN, WPS, DEBUG, ROLE><<<grid, NT, 0, st>>>(P);      // LDS is static (Lds8)
     return hipGetLastError();
 }
 
 // one launch of the narrow-counter K = 8 kernel: counter width, window class (<= 2048 / <= 5120 bases), debug dump
-hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
+hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st,
+                         bool sample = false) {
+    if (sample) {           // the 1/16 sample of the adaptive width: 4-bit counters, its own name in kernel statistics
+        if (small_w) return launch_scan8<8, 256, 8, 4, 64, 3, false, 1>(P, num_cu, work_items, st);
+        return launch_scan8<8, 256, 20, 4, 64, 3, false, 1>(P, num_cu, work_items, st);
+    }
 #define FRISK_L7(K_, ITS_, DBG_) return launch_scan8<K_, 256, ITS_, 8, 64, FRISK_K7_WPS, DBG_>(P, num_cu, work_items, st)
     if (kmax == 7) {        // K = 6, 7: the 8-bit table is 16 / 4 KiB - registers, not LDS, bound the workgroups per CU
         if (debug) { if (small_w) FRISK_L7(7, 8, true); else FRISK_L7(7, 20, true); }
@@ -1051,7 +1056,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
             ScanParams S = B;                   // the sample
             S.sel_mode = 1; S.out_list = c->d_ovf_list.p; S.out_count = c->d_ovf_count.p;
             const int64_t nsample = (nchunks + S.sel_mod - 1) / S.sel_mod;
-            HIPC(c, launch_narrow(c->kmax, 4, small_w, false, S, c->num_cu, nsample, c->stream));
+            HIPC(c, launch_narrow(c->kmax, 4, small_w, false, S, c->num_cu, nsample, c->stream, true));
             unsigned int handed = 0;
             HIPC(c, hipMemcpyAsync(&handed, c->d_ovf_count.p, sizeof(handed), hipMemcpyDeviceToHost, c->stream));
             HIPC(c, hipStreamSynchronize(c->stream));

@@ -82,9 +82,11 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
            __builtin_amdgcn_readlane(int(x), 32) + __builtin_amdgcn_readlane(int(x), 48);
 }
 
+// ROLE only names the launch (0 bulk / list, 1 the sample of the adaptive width): the code is the same, but a profiler's
+// per-kernel statistics then keep the 1/16 sample launches apart from the bulk launches.
 // NT threads, windows of at most NT*ITS bases, BITS per order-8 counter, LOGN: bins of the logarithm table, WPS: waves per SIMD the register allocation must allow (= workgroups per
 // CU * NT / 256).
-template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG>
+template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG, int ROLE = 0>
 __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     static_assert(KMAX >= 6 && KMAX <= 8, "highest order 6, 7 or 8");
     constexpr int K = KMAX, LVL = KMAX - 3;              // highest order; level of the shared prefix tables (and of the small tables' top)
