@@ -228,12 +228,26 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             fullm &= topbits(nleft - (K - 1)) & MINE;                        // ... all inside the window: a max-mer starts here
             auto code_at = [&](int it) -> uint32_t { return uint32_t(acode >> (64 - 2 * K - 2 * it)) & (NK - 1u); };     // the K-mer at position it
             {
-                uint32_t cA = 0, cT = 0, cG = 0, cC = 0, nvalid = 0;
-                auto tally = [&](bool sel, uint32_t c2) {
-                    cA += __popcll(__ballot(sel && c2 == 0));
-                    cT += __popcll(__ballot(sel && c2 == 1));
-                    cG += __popcll(__ballot(sel && c2 == 2));
-                    cC += __popcll(__ballot(sel && c2 == 3));
+                uint32_t cAll = 0, cGC = 0, nvalid = 0;
+                // The composition the row needs (calcGC L120-137, countN L106-118) is two numbers: how many bases are uppercase
+                // A/T/G/C, and how many of those are G or C - the HIGH bit of the 2-bit code (A=0,T=1,G=2,C=3).  Both are
+                // popcounts over the lane's positions once the codes' high bits are gathered into a plane (bit 31-it <->
+                // position it, like the validity masks): no per-position loop, no ballots.  (Real assemblies are soft-masked
+                // over half their length: the per-position ballots this replaces ran for almost every wave there.)
+                auto gc_plane = [&]() -> uint32_t {
+                    auto squeeze = [](uint32_t w) -> uint32_t {      // the odd bits 31, 29, ..., 1 of w -> bits 15..0
+                        uint32_t x = (w >> 1) & 0x55555555u;
+                        x = (x | (x >> 1)) & 0x33333333u;
+                        x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+                        x = (x | (x >> 4)) & 0x00FF00FFu;
+                        x = (x | (x >> 8)) & 0x0000FFFFu;
+                        return x;
+                    };
+                    return (squeeze(uint32_t(acode >> 32)) << 16) | squeeze(uint32_t(acode));
+                };
+                auto tally = [&](uint32_t sel) {                     // sel: the lane's positions to count
+                    cAll = wave_sum_u32(uint32_t(__popc(sel)));
+                    cGC = wave_sum_u32(uint32_t(__popc(sel & gc_plane())));
                 };
 #pragma unroll FRISK8_UNROLL1
                 for (int it = 0; it < ITS; ++it) {
@@ -264,16 +278,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 const uint32_t ntop = __popc(fullm);
 #pragma unroll
                 for (int b = 0; (1 << b) <= ITS; ++b) nvalid += uint32_t(__popcll(__ballot((ntop >> b) & 1u))) << b;
-                if (tally_by_ballot) {
-                    const uint32_t upm = actm & vld & ~alow;
-#pragma unroll 4
-                    for (int it = 0; it < ITS; ++it) tally((upm >> (31 - it)) & 1u, uint32_t(acode >> (62 - 2 * it)) & 3u);
-                } else {
+                if (tally_by_ballot) {              // kmin > 1: no order-1 table: count the uppercase bases directly
+                    tally(actm & vld & ~alow);
+                } else {                            // kmin = 1: the order-1 table counts ALL valid bases; subtract the soft-masked
                     const uint32_t lowm = actm & vld & alow;
-                    if (__ballot(lowm != 0)) {
-#pragma unroll 1
-                        for (int it = 0; it < ITS; ++it) tally((lowm >> (31 - it)) & 1u, uint32_t(acode >> (62 - 2 * it)) & 3u);
-                    }
+                    if (__ballot(lowm != 0)) tally(lowm);
                 }
                 {   // the code of one max-mer of this window, any: positions that start none score it with weight 0, so that
                     // every lane computes finite values and no term needs masking (which wave's wins does not matter)
@@ -285,10 +294,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     }
                 }
                 if (lane == 0) {
-                    if (cA) atomicAdd(&misc[M_UPA], cA);
-                    if (cT) atomicAdd(&misc[M_UPT], cT);
-                    if (cG) atomicAdd(&misc[M_UPG], cG);
-                    if (cC) atomicAdd(&misc[M_UPC], cC);
+                    if (cAll) atomicAdd(&misc[M_UPA], cAll);        // (M_UPA: all four bases, M_UPG: G + C)
+                    if (cGC) atomicAdd(&misc[M_UPG], cGC);
                     if (nvalid) atomicAdd(&misc[M_NVALID], nvalid);
                 }
             }
@@ -379,11 +386,13 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             __syncthreads();
 
             auto uni = [](uint32_t x) -> uint32_t { return __builtin_amdgcn_readfirstlane(x); };
-            uint32_t upA = uni(misc[M_UPA]), upT = uni(misc[M_UPT]), upG = uni(misc[M_UPG]), upC = uni(misc[M_UPC]);
-            if (!tally_by_ballot) {
-                upA = uni(small16[0]) - upA; upT = uni(small16[1]) - upT; upG = uni(small16[2]) - upG; upC = uni(small16[3]) - upC;
+            uint32_t upAll = uni(misc[M_UPA]), upGC = uni(misc[M_UPG]);
+            if (!tally_by_ballot) {             // kmin = 1: order-1 counts (all valid bases) minus the soft-masked ones
+                const uint2 c1 = *reinterpret_cast<const uint2*>(small16);      // A, T | G, C
+                upAll = uni((c1.x & 0xFFFFu) + (c1.x >> 16) + (c1.y & 0xFFFFu) + (c1.y >> 16)) - upAll;
+                upGC = uni((c1.y & 0xFFFFu) + (c1.y >> 16)) - upGC;
             }
-            const int64_t S = int64_t(upA) + upT + upG + upC;       // windowSpace (L380)
+            const int64_t S = int64_t(upAll);                       // windowSpace (L380): uppercase A + T + G + C
             const int64_t nn = n - S;                               // nnTotal of the window
             const bool keep = !(double(nn) >= 0.3 * double(n));     // N filter (L237-241 / L213)
             uint32_t status = (jump ? ROW_JUMPBACK : 0u);
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             if (nvalid_top > 0 && S >= kmin - 1 && S <= K - 1) status |= ROW_ZERO_WEIGHT;          // zero divisor on the window side
             status |= ROW_KEPT;
             if (tid == 0) {
-                P.gc[row] = __longlong_as_double((long long)((uint64_t(uint32_t(S)) << 32) | uint32_t(upG + upC)));
+                P.gc[row] = __longlong_as_double((long long)((uint64_t(uint32_t(S)) << 32) | upGC));
                 if (P.flags & 1u) {             // RIP indices (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3
                     const double qnan = __longlong_as_double(0x7FF8000000000000LL);
                     const uint32_t AT = count(2, 1), TA = count(2, 4), TG = count(2, 6), GT = count(2, 9), CA = count(2, 12), AC = count(2, 3);
