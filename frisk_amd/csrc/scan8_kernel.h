@@ -1,28 +1,32 @@
-// scan8_kernel.h - phase B at K = 8 with SEVERAL independent workgroups per CU (the default K = 8 fast path).
+// scan8_kernel.h - phase B at K = 6, 7, 8 with SEVERAL independent workgroups per CU (the default path for these orders).
 //
 // Same per-window computation as scan_kernel.h (reference frisk/__init__.py L1478-1494: crawlGenome L194-251 ->
 // computeKmers(window) L280-367 -> IvomBuild x2 L369-457 -> KLD L459-472 -> calcGC L120-137 [-> calcRIP L474-495]),
 // different data structure.  scan_kernel.h keeps the order-8 histogram as 4^8 16-bit counters = 128 KiB, so ONE
 // 512-thread workgroup owns a CU and its two waves per SIMD run the same stage between the same barriers: they want
 // the LDS pipeline at the same time and the VALU at the same time (r1 profile: VALU < 50 % busy, 52 % of wave cycles
-// waiting).  Here the order-8 table is NARROW - BITS = 8 (64 KiB) or 4 (32 KiB) per counter - so that two (three)
-// 256-thread workgroups share a CU, each on its own window and in its own stage:
-//   * stage 1   ONE non-returning ds_add per max-mer position (field of the dword `code >> 2|3`).  Nothing else is
-//               counted there: no order-6 update, no election of representatives.
-//   * stage 2   the 5-mer counts are the sums of 64 neighbouring counters: every thread sums whole 16-byte reads
-//               (v_sad_u8 / v_dot8_u32_u4), bank-swizzled; orders 4..1 follow inside wave 0 by DPP sums.  The grand
-//               total of the table must equal the number of max-mer positions; a counter that wrapped (a max-mer
-//               occurring >= 2^BITS times: poly-A, microsatellites) breaks that equality, and the window is then
-//               handed to scan_kernel.h's 16-bit form through a device-side list (second launch, same stream).
-//   * stage 4   c8, c7 = sum of 4 children, c6 = sum of 16 children come from ONE aligned LDS read (16 / 8 bytes);
-//               the few 6- and 7-mers that are not prefixes of a max-mer (window tail, next to invalid bases) sit in
-//               a short "orphan" list held in scalar registers.
-//   * sums      every max-mer POSITION adds its max-mer's terms with weight 1/c8 (c8 positions share a max-mer), so
+// waiting).  Here the order-K table is NARROW - BITS = 8 (64 KiB at K = 8) or 4 (32 KiB) per counter - so that two /
+// three (K = 8) or four (K = 6, 7) 256-thread workgroups share a CU, each on its own window and in its own stage:
+//   * stage 1   ONE non-returning ds_add per max-mer position (field BITS * (code & 3|7) of dword code >> 2|3).  Nothing
+//               else is counted there: no lower-order update, no election of representatives.
+//   * stage 2   the (K-3)-mer counts are the sums of 64 neighbouring counters: every thread sums whole 16-byte reads
+//               (v_sad_u8 / v_dot8_u32_u4), the read order rotated per lane (conflict-free); the orders below follow
+//               inside a wave by DPP sums.  The grand total of the table must equal the number of max-mer positions;
+//               a counter that wrapped (a max-mer occurring >= 2^BITS times: poly-A, microsatellites) breaks that
+//               equality, and the window is handed to the next wider form through a device-side list: 4-bit ->
+//               8-bit -> scan_kernel.h's 16-bit form (later launches on the same stream).
+//   * stage 4   c_K, c_{K-1} = sum of 4 children, c_{K-2} = sum of 16 children come from the counter's own aligned
+//               neighbourhood (8-bit: u8 + b32 + b128 reads at the code with low bits cleared; 4-bit: u16 + b64);
+//               the few (K-1)- and (K-2)-mers that are not prefixes of a max-mer (window tail, next to invalid
+//               bases) sit in a short "orphan" list held in scalar registers.
+//   * sums      every max-mer POSITION adds its max-mer's terms with weight 1/c_K (c_K positions share a max-mer), so
 //               a lane's set of terms is fixed by the window alone: plain FP64 sums in a fixed order are
-//               bit-reproducible across runs, grids and candidate ranges, without the exact (double-pair) summation
-//               that the election of representatives by atomic arrival order forced on scan_kernel.h (6 FP64
-//               instructions per term there, 1 multiply + 1 add here).
-// Windows up to NT*ITS bases, kmin <= 5 (the shared prefix level); everything else stays on scan_kernel.h.
+//               bit-reproducible across runs, grids, candidate ranges and ranks, without the exact (double-pair)
+//               summation that the election of representatives by atomic arrival order forced on scan_kernel.h (6 FP64
+//               instructions per term there, 1 multiply + 1 add here).  Positions that start no max-mer score a
+//               stand-in (a real max-mer of the window) with weight 0: no masks.
+// Windows up to NT*ITS bases, kmin <= K-3 (the shared prefix level); everything else stays on scan_kernel.h.
+// Measurements, the adaptive choice between 4 and 8 bits, and what was tried and dropped: DESIGN.md section 3.3.
 #pragma once
 #include "scan_kernel.h"
 
