@@ -521,12 +521,18 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
         sub = e.scan(5000, 1000, rip=True, c0=1234, c1=4321)                   # another range: another sample, other widths
         few = e.scan(5000, 1000, rip=True, c0=700, c1=1000)                     # same batch and geometry: the first sample's choice holds
         stat_few = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
+        e.load(seqs)                                                            # a new residency forgets the choice ...
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        other = e.scan(5000, 1000, rip=True, c0=2000, c1=2900)                  # ... and 900 windows are too few to sample: 8-bit bulk
+        stat_other = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
     assert stat[0] == expect_bulk, stat
     assert stat[1] > 50 and stat[2] > 5, stat                                  # both hand-over lists were used
     assert stat_few[0] == expect_bulk, stat_few
     for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):        # same bits whichever form scored the window
         assert np.array_equal(getattr(sub, f), getattr(res, f)[1234:4321], equal_nan=True), f
         assert np.array_equal(getattr(few, f), getattr(res, f)[700:1000], equal_nan=True), f
+        assert np.array_equal(getattr(other, f), getattr(res, f)[2000:2900], equal_nan=True), f     # 8-bit bulk == 4-bit bulk, bit for bit
+    assert stat_other[0] == 8 and stat_other[1] == 0, stat_other
     S = OC.Seqs(seqs)
     osym, ometa = OC.genome_profile(S, 1, 8)
     assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
