@@ -1122,7 +1122,9 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         std::vector<unsigned long long> h(4 * 16 * 12);
         HIPC(c, hipMemcpyAsync(h.data(), d_stamps.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
-        static const char* names[9] = {"stage1", "barrier1", "stage2", "stage3", "barrier3", "stage4", "blocksum", "cleanup+store", "endbarrier"};
+        static const char* names16[9] = {"stage1", "barrier1", "stage2", "stage3", "barrier3", "stage4", "blocksum", "cleanup+store", "endbarrier"};
+        static const char* names8[9] = {"stage1", "barrier1", "stage2a+b", "stage2b+b", "stage3+b", "stage4", "sums+b", "clear+store", "endbarrier"};
+        const char* const* names = narrow ? names8 : names16;
         double acc[9] = {0}; int cnt = 0;
         for (int b = 0; b < 4; ++b) for (int w = 4; w < 16; ++w) {
             const unsigned long long* t = &h[(b * 16 + w) * 12];

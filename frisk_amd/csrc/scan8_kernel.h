@@ -48,11 +48,11 @@ struct Lds8 {
     static constexpr uint32_t small_bytes = 2736;                                  // orders kmin..KMAX-3 as u16 bins (sized for 1..5)
     static constexpr uint32_t orphans = small + small_bytes;                       // u16[FRISK8_ORPH_CAP]
     static constexpr uint32_t NL = 1u << (2 * (KMAX - 3));                         // entries of the shared prefix tables (level KMAX-3)
-    static constexpr uint32_t pre_i = (orphans + FRISK8_ORPH_CAP * 2 + 15) / 16 * 16;   // f64[NL]: shared prefix sums ...
-    static constexpr uint32_t pre_w = pre_i + NL * 8;                              // ... and u32[NL], as in scan_kernel.h
-    static constexpr uint32_t logtab = pre_w + NL * 4;                             // {1/c_i, -ln(1/c_i)} x LOGN
-    static constexpr uint32_t rctab = logtab + uint32_t(LOGN) * 16;                // 1/c for c < 16
-    static constexpr uint32_t misc = rctab + 16 * 8;                               // counters x2, then one {Sw, Sg, T} per wave
+    static constexpr uint32_t pre = (orphans + FRISK8_ORPH_CAP * 2 + 15) / 16 * 16;     // Pre8[NL]: the shared prefix sums, 12 bytes each
+    static constexpr uint32_t logtab = pre + NL * 12;                              // {1/c_i, -ln(1/c_i)} x LOGN
+    // {1/c, c^2 r_K} for c < 16 (second half per window); the 8-bit form has 128 bytes to spare, not 256: 1/c only, the other computed
+    static constexpr uint32_t rctab = logtab + uint32_t(LOGN) * 16;
+    static constexpr uint32_t misc = rctab + 16 * (BITS == 4 ? 16 : 8);            // counters x2, then one {Sw, Sg, T} per wave
     static constexpr uint32_t t8 = (misc + 2 * FRISK8_SLOTS * 4 + uint32_t(NT / 64) * 3 * 8 + 15) / 16 * 16;
     static constexpr uint32_t t8_bytes = (1u << (2 * KMAX)) * BITS / 8;
     static constexpr uint32_t total = t8 + t8_bytes;
@@ -66,14 +66,22 @@ template <int N, int DEG>
 __device__ inline double log_tab_n(double x, const double2* tab) {
     const int k = __builtin_amdgcn_frexp_exp(x);
     const double m = __builtin_amdgcn_frexp_mant(x);
-    const uint32_t i = (uint32_t(__double2hiint(m)) >> (N == 128 ? 13 : (N == 64 ? 14 : 15))) & uint32_t(N - 1);
-    const double2 e = tab[i];
+    // (the bin's BYTE offset straight from the mantissa's top bits: shift + mask, no index scaling)
+    const uint32_t off = (uint32_t(__double2hiint(m)) >> ((N == 128 ? 13 : (N == 64 ? 14 : 15)) - 4)) & (uint32_t(N - 1) << 4);
+    const double2 e = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
     const double r = __builtin_fma(m, e.x, -1.0);
     double p = (DEG & 1) ? 1.0 / DEG : -1.0 / DEG;
 #pragma unroll
     for (int d = DEG - 1; d >= 2; --d) p = __builtin_fma(r, p, (d & 1) ? 1.0 / d : -1.0 / d);
     return __builtin_fma(double(k), 0.69314718055994530942, e.y) + __builtin_fma(r * r, p, r);
 }
+
+// shared prefix sums of one (K-3)-mer, the orders kmin..K-3 of a max-mer's two sums (as scan_kernel.h's pre_i / pre_w): numerator
+// term and integer weight, interleaved so that ONE address serves both reads of a position
+struct __attribute__((packed, aligned(4))) Pre8 {
+    double A;
+    uint32_t W;
+};
 
 template <int CTRL>
 __device__ inline uint32_t dpp_addu(uint32_t x) {
@@ -103,6 +111,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     constexpr int SHW = BITS == 8 ? 2 : 3;               // code >> SHW = dword of the table
     constexpr uint32_t PERM = (32 / BITS) - 1;           // code & PERM = field inside the dword
     using L = Lds8<KMAX, BITS, LOGN, NT>;
+    // the order-K table is cleared whole when that takes no more stores per thread than a lane has positions (measured: 64 KiB
+    // for windows of 2000 bases is the one case where every position clearing its own dword is cheaper)
+    constexpr bool CLEAR_ALL = L::t8_bytes / 16 / NT <= uint32_t(ITS);
     __shared__ __attribute__((aligned(16))) unsigned char lds[L::total];
     const int tid0 = threadIdx.x;
     const int kmin0 = P.kmin;
@@ -111,14 +122,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     uint32_t* small32 = reinterpret_cast<uint32_t*>(lds + L::small);
     uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L::small);
     uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L::orphans);
-    double* pre_i = reinterpret_cast<double*>(lds + L::pre_i);
-    uint32_t* pre_w = reinterpret_cast<uint32_t*>(lds + L::pre_w);
+    Pre8* pre = reinterpret_cast<Pre8*>(lds + L::pre);
     uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L::misc);
     double* scratch = reinterpret_cast<double*>(lds + L::misc + 2 * FRISK8_SLOTS * 4);
     const double2* logtab = reinterpret_cast<const double2*>(lds + L::logtab);
-    const double* rctab = reinterpret_cast<const double*>(lds + L::rctab);
+    double2* rstab = reinterpret_cast<double2*>(lds + L::rctab);        // (BITS == 4)
+    double* rctab = reinterpret_cast<double*>(lds + L::rctab);          // (BITS == 8)
 
     auto clear_t8 = [&]() {
+#pragma unroll
         for (int i = tid0; i < int(L::t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
     };
     auto clear_small = [&]() {
@@ -130,7 +142,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     {
         double2* lt = reinterpret_cast<double2*>(lds + L::logtab);
         for (int i = tid0; i < LOGN; i += NT) lt[i] = reinterpret_cast<const double2*>(LOGN == 128 ? P.log_tab : (LOGN == 64 ? P.log_tab64 : P.log_tab32))[i];
-        if (tid0 < 16) reinterpret_cast<double*>(lds + L::rctab)[tid0] = P.rc_tab[tid0];
+        if (tid0 < 16) {
+            if (BITS == 4) rstab[tid0] = make_double2(P.rc_tab[tid0], 0.0); else rctab[tid0] = P.rc_tab[tid0];
+        }
     }
     __syncthreads();
 
@@ -151,7 +165,28 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0; d.base0 = 0; d.j0 = 0;
     int dsi = -1;
     uint32_t parity = 0;
+#ifdef FRISK_STAMPS
+    int stamp_win = -1;         // (diagnostic builds: STAMP of scan_kernel.h - wave 0 of the first workgroups, s_memtime per stage)
+#endif
 
+    // candidate `cand` of the descriptor in `d`: first base, reported coordinates, length (crawlGenome L211-245)
+    auto window_of = [&](int64_t cand, int64_t& st, int64_t& rep_start, int64_t& rep_stop, int& n, bool& jump) {
+        const int64_t j = cand - d.cand0 + d.j0;               // window index inside the scaffold
+        jump = false;
+        if (d.kind == 1) { st = 0; n = int(d.size); rep_start = 1; rep_stop = d.size; }      // L219
+        else {
+            st = j * P.inc;
+            n = P.w;
+            rep_start = st + 1; rep_stop = st + P.w;                                        // L245
+            if (st + P.w > d.size) {                                                        // L230-232
+                jump = true;
+                st = d.size - P.w;
+                rep_start = st; rep_stop = d.size;                                          // L243: 0-based start
+                if (st < 0) { st += d.size; if (st < 0) st = 0; }                           // negative slice start
+                n = int(d.size - st);
+            }
+        }
+    };
     for (int64_t q = v; q < nchunks; q += G) {
         int64_t qq = q;                                                  // chunk index inside [c0, c1)
         if (!listed && P.sel_mode == 1) qq = q * M;
@@ -169,30 +204,29 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 }
                 d = P.descs[lo];
                 dsi = lo;
+                // (into scalar registers: the descriptor is the same for every lane, but a plain global load leaves it in vector
+                //  registers, and the window geometry below - 64-bit multiplies and compares per window - then runs on the VALU)
+                auto s64 = [](int64_t x) -> int64_t {
+                    return int64_t((uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint64_t(x) >> 32)))) << 32) |
+                                   uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uint64_t(x))))));
+                };
+                d.off = s64(d.off); d.size = s64(d.size); d.cand0 = s64(d.cand0); d.ncand = s64(d.ncand);
+                d.base0 = s64(d.base0); d.j0 = s64(d.j0); d.kind = __builtin_amdgcn_readfirstlane(d.kind);
             }
             // The thread index and the lowest order, opaque to the optimiser from here on: otherwise it hoists every
             // per-position constant that depends on them (20 x {tid*20+it, masks, table offsets}: > 100 registers and
             // dozens of spilled scalars) out of the window loop and keeps them alive across all stages.
             int tid = tid0, kmin = kmin0;
             asm volatile("" : "+v"(tid), "+s"(kmin));
+#ifdef FRISK_STAMPS
+            ++stamp_win;
+#endif
+            STAMP(0)
             const int lane = tid & 63;
-            const int64_t j = cand - d.cand0 + d.j0;           // window index inside the scaffold
             int64_t st, rep_start, rep_stop;
             int n;
             bool jump = false;
-            if (d.kind == 1) { st = 0; n = int(d.size); rep_start = 1; rep_stop = d.size; }      // L219
-            else {
-                st = j * P.inc;
-                n = P.w;
-                rep_start = st + 1; rep_stop = st + P.w;                                        // L245
-                if (st + P.w > d.size) {                                                        // L230-232
-                    jump = true;
-                    st = d.size - P.w;
-                    rep_start = st; rep_stop = d.size;                                          // L243: 0-based start
-                    if (st < 0) { st += d.size; if (st < 0) st = 0; }                           // negative slice start
-                    n = int(d.size - st);
-                }
-            }
+            window_of(cand, st, rep_start, rep_stop, n, jump);
             const int64_t g0 = d.off + (st - d.base0);            // resident position of the window's first base
             const int64_t row = cand - P.c0;
             if (n > NT * ITS) {
@@ -212,6 +246,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const int64_t gl = g0 + (j0 < n ? j0 : 0);                       // clamped: loads are unconditional
             const int64_t wi = gl >> 4, mi = gl >> 5;
             const int shc = 32 - int(gl & 15) * 2, shm = 32 - int(gl & 31);
+            // (requesting the NEXT window's words after stage 4, to have them in registers here: measured +-0 at K = 8, -2 % at
+            //  K = 6, 7 - with three or four workgroups per CU the other windows' waves already cover these two round trips)
             const uint32_t w0 = P.codes[wi], w1 = P.codes[wi + 1], w2 = P.codes[wi + 2];
             const uint32_t chi = uint32_t(((uint64_t(w0) << 32) | w1) >> shc);
             const uint32_t clo = uint32_t(((uint64_t(w1) << 32) | w2) >> shc);
@@ -303,7 +339,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     if (nvalid) atomicAdd(&misc[M_NVALID], nvalid);
                 }
             }
+            STAMP(1)
             __syncthreads();
+            STAMP(2)
             if (tid < FRISK8_SLOTS) misc_other[tid] = 0;        // the previous window's counters: nobody reads them now
 
             // ---- stage 2: C_5[q] = D_5[q] + (sum of the 64 order-8 counters below q); grand total for the overflow check
@@ -336,6 +374,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 if (lane == 0 && tot) atomicAdd(&misc[M8_TSUM], tot);
             }
             __syncthreads();
+            STAMP(3)
             // the orders below: inside a wave, no LDS round trip between the levels.  LVL >= 4: lane l of wave i takes the 4-mer
             // l + 64 i (its count comes from its four 5-mers, or is final already when LVL = 4); 3-mers are sums over quads,
             // 2-mers over rows of 16 lanes, the 1-mer i over the wave; the four quarters of the 4-mer space are independent
@@ -388,6 +427,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 }
             }
             __syncthreads();
+            STAMP(4)
 
             auto uni = [](uint32_t x) -> uint32_t { return __builtin_amdgcn_readfirstlane(x); };
             uint32_t upAll = uni(misc[M_UPA]), upGC = uni(misc[M_UPG]);
@@ -411,7 +451,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     if (fullm & (0x80000000u >> it)) t8[code_at(it) >> SHW] = 0u;
             };
             if (wrapped || !keep) {
-                if (wrapped) clear_t8(); else zero_own();
+                if (wrapped || CLEAR_ALL) clear_t8(); else zero_own();
                 clear_small();
                 if (tid == 0) {
                     if (wrapped) {
@@ -435,21 +475,26 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             if (tid == 0) { P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop; }
 
-            // The orphan list in scalar registers.  A run-7 entry is its 7-mer; a run-6 entry has bit 15 set.  o6[k] = the
-            // 6-mer of entry k (both kinds count towards c6), o7[0..n7) = the 7-mers of the run-7 entries.  A window without
-            // invalid bases has exactly one of each kind (its tail).
+            // The orphan list: its first four entries in scalar registers.  A run-(K-1) entry is its (K-1)-mer; a run-(K-2) entry
+            // has bit 15 set and holds its (K-2)-mer << 2.  o6[k] = the (K-2)-mer of entry k (both kinds count towards c6), o7[k] =
+            // the (K-1)-mer of a run-(K-1) entry.  A window without invalid bases has exactly one of each kind (its tail).
             uint32_t o6[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, o7[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            int n7 = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k < n_orph) {
                     const uint32_t e = uni(uint32_t(orph[k]));
                     o6[k] = (e >> 2) & (NK / 16u - 1u);
-                    if (!(e & 0x8000u)) {
+                    if (!(e & 0x8000u)) o7[k] = e;
+                }
+            }
+            uint32_t o7c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};     // the (K-1)-mers again, compacted: n7 of them
+            int n7 = 0;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) if (q == n7) o7[q] = e;
-                        ++n7;
-                    }
+            for (int k = 0; k < 4; ++k) {
+                if (o7[k] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q == n7) o7c[q] = o7[k];
+                    ++n7;
                 }
             }
             // what a max-mer position reads, all of it addressed by the code alone (so it can be fetched ahead of use):
@@ -468,16 +513,13 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     const uint2 x = *reinterpret_cast<const uint2*>(t8b + ((c16 >> 4) << 3));
                     f.w6 = make_uint4(x.x, x.y, 0u, 0u);
                 }
-                const uint32_t pc = c16 >> 6;
-                f.W5 = pre_w[pc];
-                f.A5 = pre_i[pc];
+                const Pre8* e = reinterpret_cast<const Pre8*>(lds + L::pre + __umul24(c16 >> 6, 12u));     // (one v_mul_u32_u24)
+                f.W5 = e->W;
+                f.A5 = e->A;
                 return f;
             };
-            // counts of the three top orders of the max-mer c16.  ORPH: what the caller knows about the orphan list -
-            // 2: at most two entries, at most one of them a 7-mer (the usual window); 4: at most four entries; 0: any length
-            auto top_counts = [&](const Fetched& f, uint32_t c16, auto orph_c, uint32_t& c8, uint32_t& c7, uint32_t& c6) __attribute__((always_inline)) {
-                constexpr int ORPH = decltype(orph_c)::value;
-                const uint32_t q6 = c16 >> 4, q7 = c16 >> 2;
+            // counts of the three top orders of the max-mer c16 as the order-K table holds them: without the orphans
+            auto table_counts = [&](const Fetched& f, uint32_t c16, uint32_t& c8, uint32_t& c7, uint32_t& c6) __attribute__((always_inline)) {
                 if (BITS == 8) {
                     c8 = f.c8;
                     c7 = __builtin_amdgcn_sad_u8(f.w7, 0u, 0u);
@@ -487,30 +529,30 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     c7 = __builtin_amdgcn_udot8(f.w7, 0x1111u, 0u, false);
                     c6 = __builtin_amdgcn_udot8(f.w6.x, 0x11111111u, __builtin_amdgcn_udot8(f.w6.y, 0x11111111u, 0u, false), false);
                 }
-                constexpr int N6 = ORPH == 2 ? 2 : 4, N7 = ORPH == 2 ? 1 : 4;
-#pragma unroll
-                for (int k = 0; k < N7; ++k) c7 += (q7 == o7[k]) ? 1u : 0u;
-#pragma unroll
-                for (int k = 0; k < N6; ++k) c6 += (q6 == o6[k]) ? 1u : 0u;
-                if (ORPH == 0)
-                    for (int k = 4; k < n_orph; ++k) {
-                        const uint32_t e = orph[k];
-                        c7 += (q7 == e) ? 1u : 0u;
-                        c6 += (q6 == ((e >> 2) & (NK / 16u - 1u))) ? 1u : 0u;
-                    }
             };
-            using orph2 = std::integral_constant<int, 2>;
-            using orph4 = std::integral_constant<int, 4>;
-            using orphN = std::integral_constant<int, 0>;
+            // ... and the orphans on top (any number of them: row metadata and the debug dump; stage 4 has its own, unrolled)
+            auto add_orphans = [&](uint32_t c16, uint32_t& c7, uint32_t& c6) __attribute__((always_inline)) {
+                const uint32_t q6 = c16 >> 4, q7 = c16 >> 2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    c7 += (q7 == o7[k]) ? 1u : 0u;
+                    c6 += (q6 == o6[k]) ? 1u : 0u;
+                }
+                for (int k = 4; k < n_orph; ++k) {
+                    const uint32_t e = orph[k];
+                    c7 += (q7 == e) ? 1u : 0u;
+                    c6 += (q6 == ((e >> 2) & (NK / 16u - 1u))) ? 1u : 0u;
+                }
+            };
             // count of the x-mer c in this window (row metadata, RIP, debug dump)
             auto count = [&](int x, uint32_t c) -> uint32_t {
                 if (x <= LVL) return small16[table_offset(kmin, x) + c];
                 uint32_t c8, c7, c6;
                 const uint32_t c16 = c << (2 * (K - x));
-                top_counts(fetch(c16), c16, orphN{}, c8, c7, c6);
+                table_counts(fetch(c16), c16, c8, c7, c6);
+                add_orphans(c16, c7, c6);
                 return x == K ? c8 : (x == K - 1 ? c7 : c6);
             };
-
             // ---- stage 3: window constants r_x = 4^x / D_x, D_x = (S-(x-1))*2 (L401-409), and the shared prefix tables
             double r_lane = 0.0;
             if (lane <= 8) r_lane = div_exact(double(1u << (2 * lane)), double(int32_t((S - (lane - 1)) * 2)));
@@ -518,6 +560,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r_lane), x),
                                         __builtin_amdgcn_readlane(__double2loint(r_lane), x));
             };
+            // the top order's terms by count: {1 / c, c^2 r_K} for c < 16 (c = 0: a position that starts no max-mer, weight 0)
+            if (BITS == 4 && tid < 16) rstab[tid].y = double(uint32_t(tid * tid)) * r_of(K);
             {
                 constexpr int LV = LVL;
                 double rx[LV + 1];
@@ -529,6 +573,37 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     ox[x] = on ? uint32_t(table_offset(kmin, x)) : 0u;
                     wm[x] = on ? 0xFFFFFFFFu : 0u;
                 }
+                if constexpr (LV == 5 && NL == 4 * NT) {
+                    // K = 8: thread t takes the four 5-mers below the 4-mer t - the orders 1..4 of the sums are theirs in common
+                    // (same operations in the same order as the generic loop below: same bits), and the four 12-byte
+                    // entries go out as three 16-byte stores
+                    const uint32_t q4 = uint32_t(tid);
+                    uint32_t W4 = 0;
+                    double A4 = 0.0;
+#pragma unroll
+                    for (int x = 1; x <= 4; ++x) {
+                        const uint32_t c = small16[ox[x] + (q4 >> (2 * (4 - x)))];
+                        const double cd = double(c);
+                        W4 += (c & wm[x]) << (2 * x);
+                        A4 = __builtin_fma(cd * cd, rx[x], A4);
+                    }
+                    const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ox[5] + 4 * q4);
+                    const uint32_t c5[4] = {ch.x & 0xFFFFu, ch.x >> 16, ch.y & 0xFFFFu, ch.y >> 16};
+                    double A5[4];
+                    uint32_t W5[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const double cd = double(c5[m]);
+                        W5[m] = W4 + ((c5[m] & wm[5]) << 10);
+                        A5[m] = __builtin_fma(cd * cd, rx[5], A4);
+                    }
+                    auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
+                    auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
+                    uint4* out = reinterpret_cast<uint4*>(pre + 4 * q4);        // four entries = 48 bytes, 16-byte aligned
+                    out[0] = make_uint4(lo(A5[0]), hi(A5[0]), W5[0], lo(A5[1]));
+                    out[1] = make_uint4(hi(A5[1]), W5[1], lo(A5[2]), hi(A5[2]));
+                    out[2] = make_uint4(W5[2], lo(A5[3]), hi(A5[3]), W5[3]);
+                } else {
 #pragma unroll 2
                 for (uint32_t c = tid; c < NL; c += NT) {
                     uint32_t cx[LV + 1];
@@ -542,11 +617,13 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         W += (cx[x] & wm[x]) << (2 * x);                    // count * 4**x (L399-408)
                         A = __builtin_fma(cd * cd, rx[x], A);               // w_x * p_x = c^2 4^x / D_x
                     }
-                    pre_i[c] = A;
-                    pre_w[c] = W;
+                    pre[c].A = A;
+                    pre[c].W = W;
+                }
                 }
             }
             __syncthreads();
+            STAMP(5)
 
             if (DEBUG && P.dbg_counts) {
                 uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
@@ -580,26 +657,38 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             //      Sw = sum Iw/c8,  Sg = sum Ig/c8,  T = sum Iw ln(Iw/Ig)/c8  over POSITIONS (= sums over distinct max-mers)
             const double r6 = r_of(K - 2), r7 = r_of(K - 1), r8 = r_of(K);      // (named for K = 8: the three orders above the prefix)
             double sw = 0.0, sg = 0.0, stt = 0.0;
-            // A position that starts no max-mer scores `safe_code` (a real max-mer of this window: finite values) with weight
-            // 1/c8 replaced by 0: it adds exactly +0.0 to every sum, and no term needs a mask.
-            auto score_one = [&](const Fetched& f, uint32_t c16, bool on, auto orph_c) __attribute__((always_inline)) {
-                uint32_t c8, c7, c6;
-                top_counts(f, c16, orph_c, c8, c7, c6);
-                double rc = rctab[(on ? c8 : 0u) & 15u];                     // 1/c8 (1.0 for the 19 in 20 max-mers seen once); [0] = 0
-                if (BITS == 8 && __builtin_expect(__any(c8 >= 16u), 0)) {     // (wave-uniform, rare: low-complexity sequence)
-                    if (on && c8 >= 16u) {                                    // beyond the table: reciprocal + two Newton steps
-                        const double dc = double(c8);
-                        double r = __builtin_amdgcn_rcp(dc);
-                        r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
-                        r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
-                        rc = r;
+            // (a << SH) + b in one instruction (the compiler's own choice for the weight below is two shifts, a shift-add and an add3)
+            auto shl_add = [](uint32_t a, auto sh, uint32_t b) __attribute__((always_inline)) -> uint32_t {
+                uint32_t r;
+                asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(decltype(sh)::value), "v"(b));
+                return r;
+            };
+            // One position, its counts known.  `sel`: the position's index into the {1/c, c^2 r_K} table - its top count, or 0
+            // where it starts no max-mer: such a position scores the stand-in code (a real max-mer of this window: finite values)
+            // with weight 0 and adds exactly +0.0 to every sum, so no term needs a mask.
+            auto score_one = [&](const Fetched& f, uint32_t c8, uint32_t c7, uint32_t c6, uint32_t sel, bool on)
+                                 __attribute__((always_inline)) {
+                double2 rs;                                                   // {1/c8 (1.0 for the 19 in 20 max-mers seen once), c8^2 r8}
+                if constexpr (BITS == 4) rs = rstab[sel & 15u];
+                else {
+                    rs = make_double2(rctab[sel & 15u], double(__umul24(sel, sel)) * r8);     // (the same product, rounded alike)
+                    if (__builtin_expect(__any(c8 >= 16u), 0)) {              // (wave-uniform, rare: low-complexity sequence)
+                        if (on && c8 >= 16u) {                                // beyond the table: reciprocal + two Newton steps
+                            const double dc = double(c8);
+                            double r = __builtin_amdgcn_rcp(dc);
+                            r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                            r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                            rs.x = r;
+                        }
                     }
                 }
-                const uint32_t W = f.W5 + (c6 << (2 * K - 4)) + (c7 << (2 * K - 2)) + (c8 << (2 * K));
-                // c^2 exactly, as integers (< 2^32), then 4^x / D_x times it
+                const uint32_t W = shl_add(c8, std::integral_constant<int, 2 * K>{},
+                                           shl_add(c7, std::integral_constant<int, 2 * K - 2>{},
+                                                   shl_add(c6, std::integral_constant<int, 2 * K - 4>{}, f.W5)));
+                // c^2 exactly, as integers (< 2^32), then 4^x / D_x times it; the top order's term comes rounded from the table
                 double A = __builtin_fma(double(__umul24(c6, c6)), r6, f.A5);
                 A = __builtin_fma(double(__umul24(c7, c7)), r7, A);
-                A = __builtin_fma(double(__umul24(c8, c8)), r8, A);
+                A = A + rs.y;
                 // Iw = A/W and Iw/Ig with ONE reciprocal: ratio = A / (W * Ig), Iw = ratio * Ig.  v_rcp_f64 (24.4 bits) + one
                 // Newton step = 2^-48.8: the ratio carries a relative error of ~2e-15 - the level of the log table's - instead
                 // of being the correctly rounded quotient (two more instructions)
@@ -607,20 +696,19 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 double rr = __builtin_amdgcn_rcp(den);
                 rr = __builtin_fma(rr, __builtin_fma(-den, rr, 1.0), rr);
                 const double ratio = A * rr;
-                const double Iwr = (ratio * f.Ig) * rc;                      // this position's share of Iw
+                const double Igr = f.Ig * rs.x;                               // this position's share of Ig ...
+                const double Iwr = ratio * Igr;                               // ... and of Iw
                 const double ln = log_tab_n<LOGN, LOGDEG>(ratio, logtab);
                 sw += Iwr;
-                sg += f.Ig * rc;
-                stt += Iwr * ln;
+                sg += Igr;
+                stt = __builtin_fma(Iwr, ln, stt);
             };
             // the lane's codes and flags again, opaque to the optimiser: without this it keeps every position's pre-shifted
             // code variants of stage 1 alive across the whole window (60 registers) instead of re-deriving them here
             uint32_t ah = uint32_t(acode >> 32), al = uint32_t(acode), fm4 = fullm;
             asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
             const uint64_t acode4 = (uint64_t(ah) << 32) | al;
-            auto code4_at = [&](int it) -> uint32_t {          // the position's max-mer, or the stand-in where it starts none
-                return ((fm4 >> (31 - it)) & 1u) ? (uint32_t(acode4 >> (64 - 2 * K - 2 * it)) & (NK - 1u)) : safe_code;
-            };
+            auto raw4_at = [&](int it) -> uint32_t { return uint32_t(acode4 >> (64 - 2 * K - 2 * it)) & (NK - 1u); };
             // Shape of the scoring loop, measured per K (bench shard / C2 shape, M windows/s):
             //   K = 8 (LDS allows 3 / 2 workgroups per CU): unrolled, groups of 2: 44.8 / 36.2; rolled, groups of 1: 43.2 / 35.6
             //   K = 6, 7 (tables of 4 / 16 KiB: registers bound the occupancy): unrolled at 3 per CU spills (26 / 24); rolled,
@@ -635,11 +723,49 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #else
             constexpr bool ROLLED = K < 8;
 #endif
-            auto score_all = [&](auto orph_c) __attribute__((always_inline)) {
-                // software pipeline, fully unrolled: the reads of group g+1 are issued before the arithmetic of group g.
-                // (A rolled loop - two groups per trip, ping-pong buffers - needs 86..129 registers and no scratch, but
-                // measured 4..6 % slower at three workgroups per CU; thread counts 320 / 384 / 512 per workgroup 18..60 %.)
-                // the rolled form: two groups per trip, ping-pong buffers (ITS is a multiple of 2 GR for GR = 1, 2)
+            // ALLON: every lane of this wave starts a max-mer at every one of its positions (three waves in four of a window
+            // without invalid bases) - no stand-in code to select, no weight to mask
+            auto score_all = [&](auto allon_c, auto orph_c) __attribute__((always_inline)) {
+                constexpr bool ALLON = decltype(allon_c)::value;
+                constexpr int ORPH = decltype(orph_c)::value;           // the orphan list holds <= 2 entries (one (K-1)-mer at most) / <= 4 / any number: 2 / 4 / 0
+                auto on_at = [&](int it) -> bool { return ALLON || ((fm4 >> (31 - it)) & 1u); };
+                auto code4_at = [&](int it) -> uint32_t {      // the position's max-mer, or the stand-in where it starts none
+                    return on_at(it) ? raw4_at(it) : safe_code;
+                };
+                // a group of GR positions: counts from the table, plus the orphans
+                auto score_group = [&](Fetched (&f)[GR], int g, auto check_c) __attribute__((always_inline)) {
+                    constexpr bool CHECK = decltype(check_c)::value;         // (the unrolled form's last group may be short)
+                    uint32_t c8[GR], c7[GR], c6[GR];
+#pragma unroll
+                    for (int k = 0; k < GR; ++k) {
+                        if (!CHECK || g + k < ITS) table_counts(f[k], code4_at(g + k), c8[k], c7[k], c6[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < GR; ++k) {
+                        if (!CHECK || g + k < ITS) {
+                            const uint32_t c16 = code4_at(g + k), q6 = c16 >> 4, q7 = c16 >> 2;
+                            constexpr int N6 = ORPH == 2 ? 2 : 4, N7 = ORPH == 2 ? 1 : 4;
+#pragma unroll
+                            for (int j = 0; j < N7; ++j) c7[k] += (q7 == o7c[j]) ? 1u : 0u;
+#pragma unroll
+                            for (int j = 0; j < N6; ++j) c6[k] += (q6 == o6[j]) ? 1u : 0u;
+                            if (ORPH == 0)
+                                for (int j = 4; j < n_orph; ++j) {
+                                    const uint32_t e = orph[j];
+                                    c7[k] += (q7 == e) ? 1u : 0u;
+                                    c6[k] += (q6 == ((e >> 2) & (NK / 16u - 1u))) ? 1u : 0u;
+                                }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < GR; ++k) {
+                        if (!CHECK || g + k < ITS) score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
+                    }
+                };
+                // software pipeline: the reads of group g+1 are issued before the arithmetic of group g.
+                // The rolled form: two groups per trip, ping-pong buffers (ITS is a multiple of 2 GR for GR = 1, 2); it needs
+                // 86..129 registers and no scratch, but measured 4..6 % slower at K = 8 and three workgroups per CU; thread counts
+                // of 320 / 384 / 512 per workgroup 18..60 % slower.
                 if constexpr (ROLLED && ITS % (2 * GR) == 0) {
                     Fetched bufA[GR], bufB[GR];
 #pragma unroll
@@ -648,14 +774,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     for (int g = 0; g < ITS; g += 2 * GR) {
 #pragma unroll
                         for (int k = 0; k < GR; ++k) bufB[k] = fetch(code4_at(g + GR + k));
-#pragma unroll
-                        for (int k = 0; k < GR; ++k) score_one(bufA[k], code4_at(g + k), (fm4 >> (31 - (g + k))) & 1u, orph_c);
+                        score_group(bufA, g, std::false_type{});
                         __builtin_amdgcn_sched_barrier(0);
                         const int gn = g + 2 * GR < ITS ? g + 2 * GR : 0;       // (the last trip fetches group 0 again, unused)
 #pragma unroll
                         for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(gn + k));
-#pragma unroll
-                        for (int k = 0; k < GR; ++k) score_one(bufB[k], code4_at(g + GR + k), (fm4 >> (31 - (g + GR + k))) & 1u, orph_c);
+                        score_group(bufB, g + GR, std::false_type{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     return;
@@ -668,22 +792,34 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     const int cur = (g / GR) & 1;
 #pragma unroll
                     for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k));
-#pragma unroll
-                    for (int k = 0; k < GR; ++k) if (g + k < ITS) score_one(buf[cur][k], code4_at(g + k), (fm4 >> (31 - (g + k))) & 1u, orph_c);
+                    score_group(buf[cur], g, std::true_type{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (n_orph <= 2 && n7 <= 1) score_all(orph2{});
-            else if (n_orph <= 4) score_all(orph4{});
-            else score_all(orphN{});
+            constexpr uint32_t ALL_MINE = uint32_t(0xFFFFFFFF00000000ull >> ITS);
+            using orph2 = std::integral_constant<int, 2>;
+            using orph4 = std::integral_constant<int, 4>;
+            using orphN = std::integral_constant<int, 0>;
+            if (n_orph <= 2 && n7 <= 1) {       // (every window without invalid bases)
+                if (__all(fm4 == ALL_MINE)) score_all(std::true_type{}, orph2{});
+                else score_all(std::false_type{}, orph2{});
+            } else if (n_orph <= 4) score_all(std::false_type{}, orph4{});
+            else score_all(std::false_type{}, orphN{});
 
             // workgroup totals in a fixed order: DPP butterfly per wave, then the NW partials in wave order
+            STAMP(6)
             sw = wave_sum_exact(sw); sg = wave_sum_exact(sg); stt = wave_sum_exact(stt);
             if (lane == 0) { double* p = scratch + (tid >> 6) * 3; p[0] = sw; p[1] = sg; p[2] = stt; }
             __syncthreads();
+            STAMP(7)
+            // behind the barrier: nobody reads the tables any more.  The whole order-K table in 16-byte stores (8 / 16 per thread at
+            // K = 8) is cheaper than every position clearing its own dword (20 tests, extracts and masked 4-byte stores per lane)
+            if constexpr (CLEAR_ALL) clear_t8();
+            else {
 #pragma unroll 4
-            for (int it = 0; it < ITS; ++it)                // behind the barrier: nobody reads the tables any more
-                if (fm4 & (0x80000000u >> it)) t8[code4_at(it) >> SHW] = 0u;
+                for (int it = 0; it < ITS; ++it)
+                    if (fm4 & (0x80000000u >> it)) t8[raw4_at(it) >> SHW] = 0u;
+            }
             clear_small();
             if (tid == 0) {
                 double a = 0.0, b = 0.0, c = 0.0;
@@ -693,7 +829,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 P.sg[row] = b;
                 P.kld[row] = c;                             // T; finish_rows_kernel turns (T, Sw, Sg) into the KLD
             }
+            STAMP(8)
             __syncthreads();
+            STAMP(9)
         }
     }
 }
