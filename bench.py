@@ -191,8 +191,8 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="scale every scaffold length of the shard (testing only; 1.0 = the named workload)")
     ap.add_argument("--cpu-windows", type=int, default=150, help="windows in the CPU-baseline sample, ~0.1 s each (0 = skip)")

@@ -34,6 +34,9 @@
 #ifndef FRISK8_UNROLL1
 #define FRISK8_UNROLL1 2           // unroll factor of the stage-1 position loop
 #endif
+#ifndef FRISK8_SHORT_LANES
+#define FRISK8_SHORT_LANES 6        // stage 1: up to this many lanes of a wave with short words get a pass each (more: per position)
+#endif
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
 enum { M8_TSUM = 6,                // misc slots: grand total of the order-8 table (overflow check) ...
@@ -241,7 +244,6 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             parity ^= 1u;
 
             // ---- stage 1: one pass over the window's positions (a lane owns ITS consecutive ones) -----------
-            const bool tally_by_ballot = (kmin != 1);
             const int j0 = tid * ITS;
             const int64_t gl = g0 + (j0 < n ? j0 : 0);                       // clamped: loads are unconditional
             const int64_t wi = gl >> 4, mi = gl >> 5;
@@ -289,41 +291,58 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     cAll = wave_sum_u32(uint32_t(__popc(sel)));
                     cGC = wave_sum_u32(uint32_t(__popc(sel & gc_plane())));
                 };
+                // a position next to an invalid base or the window's end: the longest valid word there has 0..K-1 bases.
+                // Orders <= K-3 count it in the small tables (at order min(run, K-3): lower orders follow by
+                // marginalisation); a (K-2)- or (K-1)-base word is not a prefix of any counted max-mer: orphan list.
+                auto short_word = [&](uint32_t c16, uint32_t inv8, int rem) {
+                    int run = lead_clear8(inv8);
+                    run = run < rem ? run : rem;
+                    run = run < K ? run : K - 1;                         // (a K-mer inside the window would have been a max-mer)
+                    const int rs = run < LVL ? run : LVL;
+                    if (rs >= kmin) {
+                        const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (2 * K - 2 * rs));
+                        atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
+                    }
+                    if (run >= K - 2) {
+                        const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
+                        if (slot < FRISK8_ORPH_CAP)
+                            orph[slot] = uint16_t(run == K - 1 ? (c16 >> 2) : (0x8000u | ((c16 >> 4) << 2)));
+                    }
+                };
+                const uint32_t shortm = actm & ~fullm;                   // the lane's positions of that kind
+                const unsigned long long short_lanes = __ballot(shortm != 0u);
+                const bool few = __popcll(short_lanes) <= FRISK8_SHORT_LANES;
 #pragma unroll FRISK8_UNROLL1
                 for (int it = 0; it < ITS; ++it) {
                     const uint32_t bit = 0x80000000u >> it;
                     const uint32_t c16 = code_at(it);
-                    if (fullm & bit) {
-                        atomicAdd(&t8[c16 >> SHW], 1u << ((c16 & PERM) * BITS));
-                    } else if (actm & bit) {
-                        // next to an invalid base or the window's end: the longest valid word here has 0..7 bases.
-                        // Orders <= 5 count it in the small tables (at order min(run, 5): lower orders follow by
-                        // marginalisation); a 6- or 7-base word is not a prefix of any counted max-mer: orphan list.
-                        int run = lead_clear8((ainv >> (24 - it)) & 0xFFu);
-                        const int rem = n - (j0 + it);
-                        run = run < rem ? run : rem;
-                        run = run < K ? run : K - 1;                         // (a K-mer inside the window would have been a max-mer)
-                        const int rs = run < LVL ? run : LVL;
-                        if (rs >= kmin) {
-                            const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (2 * K - 2 * rs));
-                            atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
-                        }
-                        if (run >= K - 2) {
-                            const uint32_t slot = atomicAdd(&misc[M_NORPH], 1u);
-                            if (slot < FRISK8_ORPH_CAP)
-                                orph[slot] = uint16_t(run == K - 1 ? (c16 >> 2) : (0x8000u | ((c16 >> 4) << 2)));
+                    if (fullm & bit) atomicAdd(&t8[c16 >> SHW], 1u << ((c16 & PERM) * BITS));
+                    else if (!few && (shortm & bit)) short_word(c16, (ainv >> (24 - it)) & 0xFFu, n - (j0 + it));
+                }
+                // Few lanes with such positions (a window's last lane: K-1 of them in a row; the edges of an invalid run): one
+                // pass per LANE with its positions spread over the wave's lanes, instead of one exec-masked pass per position
+                // inside the loop above - the other three waves of the workgroup wait at the barrier for this lane.
+                if (few) {
+                    for (unsigned long long rest = short_lanes; rest; rest &= rest - 1) {
+                        const int src = int(__ffsll((long long)rest)) - 1;
+                        const uint32_t sm = uint32_t(__builtin_amdgcn_readlane(int(shortm), src));
+                        const uint32_t si = uint32_t(__builtin_amdgcn_readlane(int(ainv), src));
+                        const uint32_t sh = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(acode >> 32)), src));
+                        const uint32_t sl = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(acode)), src));
+                        const int sleft = __builtin_amdgcn_readlane(nleft, src);
+                        const int it = lane < ITS ? lane : 0;
+                        if (lane < ITS && ((sm >> (31 - it)) & 1u)) {
+                            const uint64_t sc = (uint64_t(sh) << 32) | sl;
+                            short_word(uint32_t(sc >> (64 - 2 * K - 2 * it)) & (NK - 1u), (si >> (24 - it)) & 0xFFu, sleft - it);
                         }
                     }
                 }
                 const uint32_t ntop = __popc(fullm);
 #pragma unroll
                 for (int b = 0; (1 << b) <= ITS; ++b) nvalid += uint32_t(__popcll(__ballot((ntop >> b) & 1u))) << b;
-                if (tally_by_ballot) {              // kmin > 1: no order-1 table: count the uppercase bases directly
-                    tally(actm & vld & ~alow);
-                } else {                            // kmin = 1: the order-1 table counts ALL valid bases; subtract the soft-masked
-                    const uint32_t lowm = actm & vld & alow;
-                    if (__ballot(lowm != 0)) tally(lowm);
-                }
+                // (the order-1 table could give these two when kmin = 1, but only after the marginalisation - which now runs
+                //  inside stage 3, where the window constants made from them are already needed)
+                tally(actm & vld & ~alow);
                 {   // the code of one max-mer of this window, any: positions that start none score it with weight 0, so that
                     // every lane computes finite values and no term needs masking (which wave's wins does not matter)
                     const unsigned long long have = __ballot(fullm != 0u);
@@ -375,43 +394,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             __syncthreads();
             STAMP(3)
-            // the orders below: inside a wave, no LDS round trip between the levels.  LVL >= 4: lane l of wave i takes the 4-mer
-            // l + 64 i (its count comes from its four 5-mers, or is final already when LVL = 4); 3-mers are sums over quads,
-            // 2-mers over rows of 16 lanes, the 1-mer i over the wave; the four quarters of the 4-mer space are independent
-            // (one wave each; a workgroup of fewer waves loops).  LVL = 3: one wave, lane l = the 3-mer l.
-            if constexpr (LVL >= 4) {
-                if (tid < 256 && kmin <= 4 && (LVL == 5 || kmin <= 3)) {
-                    const uint32_t o4 = uint32_t(table_offset(kmin, 4));
-                    for (int i = tid >> 6; i < 4; i += (NT >= 256 ? 4 : NT / 64)) {
-                        const uint32_t q4 = uint32_t(tid & 63) + 64u * i;
-                        uint32_t c4 = small16[o4 + q4];
-                        if constexpr (LVL == 5) {
-                            const uint2 ch = *reinterpret_cast<const uint2*>(small16 + o5 + 4 * q4);
-                            c4 += (ch.x & 0xFFFFu) + (ch.x >> 16) + (ch.y & 0xFFFFu) + (ch.y >> 16);
-                            small16[o4 + q4] = uint16_t(c4);
-                        }
-                        if (kmin <= 3) {
-                            uint32_t qs = dpp_addu<0xB1>(c4);
-                            qs = dpp_addu<0x4E>(qs);                                             // the quad's sum, in all four lanes
-                            const uint32_t o3 = uint32_t(table_offset(kmin, 3));
-                            uint32_t c3 = 0;
-                            if ((lane & 3) == 0) { c3 = small16[o3 + (lane >> 2) + 16 * i] + qs; small16[o3 + (lane >> 2) + 16 * i] = uint16_t(c3); }
-                            if (kmin <= 2) {
-                                uint32_t rs = dpp_addu<0xB1>(c3);
-                                rs = dpp_addu<0x4E>(rs); rs = dpp_addu<0x141>(rs); rs = dpp_addu<0x140>(rs);   // the row's four C_3
-                                const uint32_t o2 = uint32_t(table_offset(kmin, 2));
-                                uint32_t c2 = 0;
-                                if ((lane & 15) == 0) { c2 = small16[o2 + (lane >> 4) + 4 * i] + rs; small16[o2 + (lane >> 4) + 4 * i] = uint16_t(c2); }
-                                if (kmin <= 1) {
-                                    const uint32_t ws = __builtin_amdgcn_readlane(int(c2), 0) + __builtin_amdgcn_readlane(int(c2), 16) +
-                                                        __builtin_amdgcn_readlane(int(c2), 32) + __builtin_amdgcn_readlane(int(c2), 48);
-                                    if (lane == 0) small16[i] = uint16_t(small16[i] + ws);
-                                }
-                            }
-                        }
-                    }
-                }
-            } else {
+            // The orders below follow inside a wave, no LDS round trip between the levels.  LVL >= 4 (K = 7, 8): as part of
+            // stage 3, where thread t holds the 4-mer t anyway.  LVL = 3 (K = 6): here - one wave, lane l = the 3-mer l.
+            if constexpr (LVL == 3) {
                 if (tid < 64 && kmin <= 2) {
                     const uint32_t c3 = small16[uint32_t(table_offset(kmin, 3)) + uint32_t(tid)];     // final already
                     uint32_t qs = dpp_addu<0xB1>(c3);
@@ -425,17 +410,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         if ((tid & 15) == 0) small16[tid >> 4] = uint16_t(small16[tid >> 4] + rs);
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
             STAMP(4)
 
             auto uni = [](uint32_t x) -> uint32_t { return __builtin_amdgcn_readfirstlane(x); };
-            uint32_t upAll = uni(misc[M_UPA]), upGC = uni(misc[M_UPG]);
-            if (!tally_by_ballot) {             // kmin = 1: order-1 counts (all valid bases) minus the soft-masked ones
-                const uint2 c1 = *reinterpret_cast<const uint2*>(small16);      // A, T | G, C
-                upAll = uni((c1.x & 0xFFFFu) + (c1.x >> 16) + (c1.y & 0xFFFFu) + (c1.y >> 16)) - upAll;
-                upGC = uni((c1.y & 0xFFFFu) + (c1.y >> 16)) - upGC;
-            }
+            const uint32_t upAll = uni(misc[M_UPA]), upGC = uni(misc[M_UPG]);
             const int64_t S = int64_t(upAll);                       // windowSpace (L380): uppercase A + T + G + C
             const int64_t nn = n - S;                               // nnTotal of the window
             const bool keep = !(double(nn) >= 0.3 * double(n));     // N filter (L237-241 / L213)
@@ -573,53 +553,88 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     ox[x] = on ? uint32_t(table_offset(kmin, x)) : 0u;
                     wm[x] = on ? 0xFFFFFFFFu : 0u;
                 }
-                if constexpr (LV == 5 && NL == 4 * NT) {
-                    // K = 8: thread t takes the four 5-mers below the 4-mer t - the orders 1..4 of the sums are theirs in common
-                    // (same operations in the same order as the generic loop below: same bits), and the four 12-byte
-                    // entries go out as three 16-byte stores
+                if constexpr (LV >= 4) {
+                    // K = 7, 8: thread t takes the 4-mer t.  Its count is final (K = 7) or follows from its four 5-mers (K = 8);
+                    // the 3-mers are sums over quads of lanes, the 2-mers over rows of 16, the 1-mer i over wave i - DPP, no
+                    // LDS round trip and no barrier between the levels (this was a stage of its own).  The finished counts go
+                    // back to the small tables (RIP indices, debug dump) and, from registers, into the prefix sums.
+                    static_assert(NT == 256, "thread t <-> 4-mer t");
                     const uint32_t q4 = uint32_t(tid);
+                    uint32_t c5[4] = {0u, 0u, 0u, 0u};
+                    if constexpr (LV == 5) {
+                        const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ox[5] + 4 * q4);
+                        c5[0] = ch.x & 0xFFFFu; c5[1] = ch.x >> 16; c5[2] = ch.y & 0xFFFFu; c5[3] = ch.y >> 16;
+                    }
+                    uint32_t cx[5] = {0u, 0u, 0u, 0u, 0u};
+                    if (kmin <= 4) {
+                        cx[4] = small16[ox[4] + q4];
+                        if constexpr (LV == 5) {
+                            cx[4] += c5[0] + c5[1] + c5[2] + c5[3];
+                            small16[ox[4] + q4] = uint16_t(cx[4]);
+                        }
+                        if (kmin <= 3) {
+                            uint32_t qs = dpp_addu<0xB1>(cx[4]);
+                            qs = dpp_addu<0x4E>(qs);                                             // the quad's sum, in all four lanes
+                            cx[3] = small16[ox[3] + (q4 >> 2)] + qs;                             // (every lane of the quad reads, then one writes)
+                            if ((lane & 3) == 0) small16[ox[3] + (q4 >> 2)] = uint16_t(cx[3]);
+                            if (kmin <= 2) {
+                                uint32_t rs = dpp_addu<0xB1>((lane & 3) == 0 ? cx[3] : 0u);
+                                rs = dpp_addu<0x4E>(rs); rs = dpp_addu<0x141>(rs); rs = dpp_addu<0x140>(rs);   // the row's four C_3, in all 16 lanes
+                                cx[2] = small16[ox[2] + (q4 >> 4)] + rs;
+                                if ((lane & 15) == 0) small16[ox[2] + (q4 >> 4)] = uint16_t(cx[2]);
+                                if (kmin <= 1) {
+                                    const uint32_t ws = __builtin_amdgcn_readlane(int(cx[2]), 0) + __builtin_amdgcn_readlane(int(cx[2]), 16) +
+                                                        __builtin_amdgcn_readlane(int(cx[2]), 32) + __builtin_amdgcn_readlane(int(cx[2]), 48);
+                                    cx[1] = small16[q4 >> 6] + ws;
+                                    if (lane == 0) small16[q4 >> 6] = uint16_t(cx[1]);
+                                }
+                            }
+                        }
+                    }
                     uint32_t W4 = 0;
                     double A4 = 0.0;
 #pragma unroll
-                    for (int x = 1; x <= 4; ++x) {
-                        const uint32_t c = small16[ox[x] + (q4 >> (2 * (4 - x)))];
-                        const double cd = double(c);
-                        W4 += (c & wm[x]) << (2 * x);
+                    for (int x = 1; x <= 4; ++x) {                  // (same operations in the same order as the generic loop below: same bits)
+                        const double cd = double(cx[x]);
+                        W4 += (cx[x] & wm[x]) << (2 * x);
                         A4 = __builtin_fma(cd * cd, rx[x], A4);
                     }
-                    const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ox[5] + 4 * q4);
-                    const uint32_t c5[4] = {ch.x & 0xFFFFu, ch.x >> 16, ch.y & 0xFFFFu, ch.y >> 16};
-                    double A5[4];
-                    uint32_t W5[4];
+                    if constexpr (LV == 4) {
+                        pre[q4].A = A4;
+                        pre[q4].W = W4;
+                    } else {
+                        double A5[4];
+                        uint32_t W5[4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const double cd = double(c5[m]);
-                        W5[m] = W4 + ((c5[m] & wm[5]) << 10);
-                        A5[m] = __builtin_fma(cd * cd, rx[5], A4);
+                        for (int m = 0; m < 4; ++m) {
+                            const double cd = double(c5[m]);
+                            W5[m] = W4 + ((c5[m] & wm[5]) << 10);
+                            A5[m] = __builtin_fma(cd * cd, rx[5], A4);
+                        }
+                        auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
+                        auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
+                        uint4* out = reinterpret_cast<uint4*>(pre + 4 * q4);        // four entries = 48 bytes, 16-byte aligned
+                        out[0] = make_uint4(lo(A5[0]), hi(A5[0]), W5[0], lo(A5[1]));
+                        out[1] = make_uint4(hi(A5[1]), W5[1], lo(A5[2]), hi(A5[2]));
+                        out[2] = make_uint4(W5[2], lo(A5[3]), hi(A5[3]), W5[3]);
                     }
-                    auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
-                    auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
-                    uint4* out = reinterpret_cast<uint4*>(pre + 4 * q4);        // four entries = 48 bytes, 16-byte aligned
-                    out[0] = make_uint4(lo(A5[0]), hi(A5[0]), W5[0], lo(A5[1]));
-                    out[1] = make_uint4(hi(A5[1]), W5[1], lo(A5[2]), hi(A5[2]));
-                    out[2] = make_uint4(W5[2], lo(A5[3]), hi(A5[3]), W5[3]);
                 } else {
 #pragma unroll 2
-                for (uint32_t c = tid; c < NL; c += NT) {
-                    uint32_t cx[LV + 1];
+                    for (uint32_t c = tid; c < NL; c += NT) {
+                        uint32_t cx[LV + 1];
 #pragma unroll
-                    for (int x = 1; x <= LV; ++x) cx[x] = small16[ox[x] + (c >> (2 * (LV - x)))];
-                    uint32_t W = 0;
-                    double A = 0.0;
+                        for (int x = 1; x <= LV; ++x) cx[x] = small16[ox[x] + (c >> (2 * (LV - x)))];
+                        uint32_t W = 0;
+                        double A = 0.0;
 #pragma unroll
-                    for (int x = 1; x <= LV; ++x) {
-                        const double cd = double(cx[x]);
-                        W += (cx[x] & wm[x]) << (2 * x);                    // count * 4**x (L399-408)
-                        A = __builtin_fma(cd * cd, rx[x], A);               // w_x * p_x = c^2 4^x / D_x
+                        for (int x = 1; x <= LV; ++x) {
+                            const double cd = double(cx[x]);
+                            W += (cx[x] & wm[x]) << (2 * x);                    // count * 4**x (L399-408)
+                            A = __builtin_fma(cd * cd, rx[x], A);               // w_x * p_x = c^2 4^x / D_x
+                        }
+                        pre[c].A = A;
+                        pre[c].W = W;
                     }
-                    pre[c].A = A;
-                    pre[c].W = W;
-                }
                 }
             }
             __syncthreads();

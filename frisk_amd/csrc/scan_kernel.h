@@ -92,11 +92,14 @@ struct ScanParams {
 
 #pragma clang fp contract(off)
 
-// Diagnostic builds only (-DFRISK_STAMPS): wave 0 of the first 4 workgroups records s_memtime at up to 12 points of its first
+// Diagnostic builds only (-DFRISK_STAMPS): wave FRISK_STAMP_WAVE (0) of the first 4 workgroups records s_memtime at up to 12 points of its first
 // 16 windows; the launcher prints the per-stage cycle differences.  Never in the product library.
 #ifdef FRISK_STAMPS
+#ifndef FRISK_STAMP_WAVE
+#define FRISK_STAMP_WAVE 0
+#endif
 #define STAMP(i)                                                                                          \
-    if (tid == 0 && blockIdx.x < 4 && stamp_win < 16)                                                     \
+    if (tid == 64 * FRISK_STAMP_WAVE && blockIdx.x < 4 && stamp_win < 16)                                 \
         P.stamps[(blockIdx.x * 16 + stamp_win) * 12 + (i)] = __builtin_amdgcn_s_memtime();
 #else
 #define STAMP(i)
