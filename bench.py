@@ -242,11 +242,12 @@ def main(argv=None):
     def step():
         eng.profile_reset()
         eng.profile_add(mask_host=False)
-        t_prof = eng.kernel_ms(1)
         eng.profile_allreduce()
         eng.profile_finalize()
-        res = eng.scan(W, INC, pinned=True)
-        return res, t_prof, eng.kernel_ms(0)
+        res = eng.scan(W, INC, pinned=True)                 # returns when the rows are in host memory
+        # (kernel timers are read AFTER the step's work is queued: reading the profile kernel's events earlier would park
+        #  the host on them and delay the launches behind)
+        return res, eng.kernel_ms(1), eng.kernel_ms(0)
 
     def fence():
         if dist is not None:
@@ -262,9 +263,9 @@ def main(argv=None):
         res, tp, ts = step()
         scan_ms.append(ts)
         prof_ms.append(tp)
-        rows = int(res.kept.sum())
     fence()
     elapsed = time.perf_counter() - t0
+    rows = int(res.kept.sum())                              # (every step emits the same rows: counted once, outside the timed region)
     if dist is not None:
         t = torch.tensor([elapsed, float(rows), float(total_bases), float(n_cand)], dtype=torch.float64, device="cuda")
         tmax = t.clone()
@@ -285,7 +286,7 @@ def main(argv=None):
         # algorithmic bytes of one scan launch: 2-bit bases once, 40 B per emitted row, genome table once
         b_alg = 0.25 * total_bases + 40.0 * rows + 8.0 * sum(4 ** x for x in range(KMIN, KMAX + 1))
         achieved = b_alg / (scan_avg * 1e-3) / 1e9
-        width, handed8, handed16 = eng.scan_stat()
+        width, handed8, handed16, row_segments = eng.scan_stat()
         traffic, binding, pmc_src = None, None, None
         # HBM traffic and issue counters: rocprofv3 --pmc passes of THIS workload, collected offline (separate runs, never
         # combined with tracing) and committed; valid only for the same shard and the same kernel
@@ -311,9 +312,10 @@ def main(argv=None):
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
             "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
             "scan_counter_width": {"bulk_bits": width, "windows_handed_to_8bit": handed8, "windows_handed_to_16bit": handed16},
+            "scan_row_segments": row_segments,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
-                         "kernel": "scan8_kernel (+ its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them)",
+                         "kernel": "scan8_kernel: the two bulk launches of a scan (15/16 of the rows, and the last 1/16 on a second stream while the first rows go to the host) + its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them",
                          "algorithmic_bytes_per_launch": b_alg,
                          "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
                                  "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding`"},

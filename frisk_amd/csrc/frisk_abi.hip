@@ -94,6 +94,8 @@ struct frisk_ctx {
     Batch& b() { return bat[cur]; }
     const Batch& b() const { return bat[cur]; }
     hipStream_t copy_stream = nullptr;      // uploads + packing of the staged batch
+    hipStream_t tail_stream = nullptr;      // frisk_scan: the last sixteenth of a long scan, while the rows of the rest go to the host
+    hipEvent_t ev_fork = nullptr, ev_tail_kernels = nullptr, ev_tail_done = nullptr;
     hipEvent_t staged_ev = nullptr;         // recorded behind the staged batch's last operation
     bool staged = false;
 
@@ -101,8 +103,8 @@ struct frisk_ctx {
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
     DevBuf<double> d_ig, d_logtab, d_logtab64, d_logtab32, d_rctab;
     DevBuf<int64_t> d_ovf_list, d_ovf_list2;   // windows handed from 4-bit to 8-bit counters, and from there to the 16-bit form
-    DevBuf<unsigned int> d_ovf_count;          // [0], [1]: their numbers
-    int64_t scan_stat[3] = {0, 0, 0};          // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16
+    DevBuf<unsigned int> d_ovf_count;          // [0], [1]: their numbers, [2], [3]: chunk counters of the bulk and 8-bit launches; [4..7]: the same for the scan's tail segment
+    int64_t scan_stat[4] = {0, 0, 0, 0};       // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16, row segments
     DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
     DevBuf<int64_t> d_meta;          // {totalLen, exMax, nnTotal} of the finalised profile, on the device
     int64_t* h_meta = nullptr;       // page-locked mirror, valid after the stream has been synchronised
@@ -395,6 +397,10 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
     HIPC(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPC(c, hipEventCreateWithFlags(&c->staged_ev, hipEventDisableTiming));
+    HIPC(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
+    HIPC(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPC(c, hipEventCreateWithFlags(&c->ev_tail_kernels, hipEventDisableTiming));
+    HIPC(c, hipEventCreateWithFlags(&c->ev_tail_done, hipEventDisableTiming));
     HIPC(c, hipEventCreate(&c->ev0));
     HIPC(c, hipEventCreate(&c->ev1));
     HIPC(c, c->d_raw.reserve(size_t(c->nprof) + 4));
@@ -425,7 +431,7 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
         for (int i = 1; i < 256; ++i) rc[i] = 1.0 / double(i);
         HIPC(c, c->d_rctab.reserve(256));
         HIPC(c, hipMemcpyAsync(c->d_rctab.p, rc, sizeof(rc), hipMemcpyHostToDevice, c->stream));
-        HIPC(c, c->d_ovf_count.reserve(4));
+        HIPC(c, c->d_ovf_count.reserve(8));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -443,6 +449,10 @@ void frisk_destroy(frisk_ctx* c) {
     c->o_ivom.release(); c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->staged_ev) (void)hipEventDestroy(c->staged_ev);
+    if (c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); (void)hipStreamDestroy(c->tail_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_tail_kernels) (void)hipEventDestroy(c->ev_tail_kernels);
+    if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
     if (c->h_meta) (void)hipHostFree(c->h_meta);
     if (c->evp0) (void)hipEventDestroy(c->evp0);
     if (c->evp1) (void)hipEventDestroy(c->evp1);
@@ -840,10 +850,12 @@ int frisk_profile_finalize(frisk_ctx* c) {
     HIPC(c, hipSetDevice(c->device));
     const size_t nraw = size_t(c->nprof) + 4;
     HIPC(c, hipMemcpyAsync(c->d_cnt.p, c->d_raw.p, nraw * 8, hipMemcpyDeviceToDevice, c->stream));
-    for (int x = c->kmax - 1; x >= c->kmin; --x) {
+    int x = c->kmax - 1;
+    for (; x >= c->kmin && x > 7; --x) {                // the wide levels (K > 8): one launch per order
         const int64_t n = int64_t(1) << (2 * x);
         marginalize_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(c->d_cnt.p, c->kmin, x);
     }
+    if (x >= c->kmin) marginalize_low_kernel<<<1, 1024, 0, c->stream>>>(c->d_cnt.p, c->kmin, x);       // orders <= 7: one launch
     symmetrize_kernel<<<grid_for(c->nprof, 256, 1 << 20), 256, 0, c->stream>>>(c->d_cnt.p, c->d_sym.p, c->kmin, c->kmax);
     HIPC(c, hipGetLastError());
     // metadata of L356-359 (totalLen, exMax, nnTotal): computed on the device, mirrored to the host asynchronously
@@ -976,8 +988,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
     P.stamps = nullptr;
     P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
-    P.sel_mode = 0; P.sel_mod = 16;
-    c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0;
+    P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr;
+    c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0; c->scan_stat[3] = 1;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
     HIPC(c, d_stamps.reserve(4 * 16 * 12));
@@ -1015,8 +1027,46 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     // K = 6, 7: the same kernel with 8-bit counters (a K-mer must occur 256 times in a window to wrap one)
     const bool narrow7 = (c->kmax == 6 || c->kmax == 7) && c->kmin <= c->kmax - 3 && w <= 5120 && c->plan_maxwin <= 65535 && width != 16;
     const bool narrow = narrow8 || narrow7;
+    // the 16-bit form (scan_kernel.h) over the candidates that PP names, by window class
+    auto launch16 = [&](const ScanParams& PP, int g, hipStream_t st) -> hipError_t {
+        hipError_t le;
+#define FRISK_LAUNCH16(NT_, K8_, ITS_, DBG_) le = launch_scan<NT_, K8_, ITS_, DBG_>(PP, g, L.total, st)
+        if (k8) {
+            if (debug) { if (its) FRISK_LAUNCH16(512, true, 16, true); else FRISK_LAUNCH16(1024, true, 0, true); }
+            else if (its == 4) FRISK_LAUNCH16(512, true, 4, false);
+            else if (its == 10) FRISK_LAUNCH16(512, true, 10, false);
+            else if (its == 16) FRISK_LAUNCH16(512, true, 16, false);
+            else FRISK_LAUNCH16(1024, true, 0, false);
+        } else {
+            if (debug) { if (its) FRISK_LAUNCH16(512, false, 16, true); else FRISK_LAUNCH16(1024, false, 0, true); }
+            else if (its == 4) FRISK_LAUNCH16(512, false, 4, false);
+            else if (its == 10) FRISK_LAUNCH16(512, false, 10, false);
+            else if (its == 16) FRISK_LAUNCH16(512, false, 16, false);
+            else FRISK_LAUNCH16(1024, false, 0, false);
+        }
+#undef FRISK_LAUNCH16
+        return le;
+    };
+    // rows [r0, r1) to the caller's buffers
+    auto copy_rows = [&](int64_t r0, int64_t r1, hipStream_t st) -> int {
+        const size_t m = size_t(r1 - r0);
+        HIPC(c, hipMemcpyAsync(seq_index + r0, c->o_seq.p + r0, m * 4, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(start + r0, c->o_start.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(stop + r0, c->o_stop.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(status + r0, c->o_status.p + r0, m * 4, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(kld + r0, c->o_kld.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(gc + r0, c->o_gc.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+        if (rip) {
+            HIPC(c, hipMemcpyAsync(pi + r0, c->o_pi.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(si + r0, c->o_si.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(cri + r0, c->o_cri.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+        }
+        return FRISK_OK;
+    };
+    bool rows_sent = false;                 // the narrow-counter path finishes and ships its rows itself, in two segments
+    unsigned int novf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, novf_sample[2] = {0, 0};
     HIPC(c, hipEventRecord(c->ev0, c->stream));
-    hipError_t e;
+    hipError_t e = hipSuccess;
     if (c->plan_maxwin > 65535 || c->kmax > 8) {
         // windows beyond the 16-bit LDS counters, and every window at K > 8: 32-bit tables of all orders in a global scratch
         // slice per workgroup
@@ -1040,66 +1090,119 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         // results do not depend on the choice, on the grid, or on the candidate range.
         HIPC(c, c->d_ovf_list.reserve(N));
         HIPC(c, c->d_ovf_list2.reserve(N));
-        HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 4 * sizeof(unsigned int), c->stream));
+        HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 8 * sizeof(unsigned int), c->stream));
         const bool small_w = w <= 2048;
         int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), 8));
         if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk8 = std::max<int64_t>(1, std::atoll(ev));
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
-        ScanParams B = P;                       // the bulk launch over [c0, c1)
-        B.chunk = int32_t(chunk8);
         int bulk = (width == 4 && narrow8) ? 4 : 8;
+        int sel_mode = 0;
         frisk_ctx::Batch& RB = c->b();
         const bool hinted = RB.width_hint != 0 && RB.hint_w == w && RB.hint_inc == inc;
         if (narrow7) { /* 8-bit bulk, no sample */ }
         else if (width == 0 && !debug && hinted) bulk = RB.width_hint;      // same batch, same geometry: the earlier sample still holds
-        else if (width == 0 && !debug && nchunks >= 64 * B.sel_mod) {
-            ScanParams S = B;                   // the sample
-            S.sel_mode = 1; S.out_list = c->d_ovf_list.p; S.out_count = c->d_ovf_count.p;
+        else if (width == 0 && !debug && nchunks >= 64 * P.sel_mod) {
+            ScanParams S = P;                   // the sample
+            S.chunk = int32_t(chunk8);
+            S.sel_mode = 1; S.out_list = c->d_ovf_list.p; S.out_count = c->d_ovf_count.p; S.queue = c->d_ovf_count.p + 2;
             const int64_t nsample = (nchunks + S.sel_mod - 1) / S.sel_mod;
             HIPC(c, launch_narrow(c->kmax, 4, small_w, false, S, c->num_cu, nsample, c->stream, true));
             unsigned int handed = 0;
             HIPC(c, hipMemcpyAsync(&handed, c->d_ovf_count.p, sizeof(handed), hipMemcpyDeviceToHost, c->stream));
             HIPC(c, hipStreamSynchronize(c->stream));
-            // 4-bit pays while fewer than about one window in five has to be redone (measured: 21.6 ns per window with
-            // 4-bit counters, 27.5 ns with 8-bit; redoing costs another 27.5)
+            // 4-bit pays while fewer than about one window in five has to be redone (measured: 20 ns per window with
+            // 4-bit counters, 25 ns with 8-bit; redoing costs another 25)
             bulk = (double(handed) <= 0.2 * double(nsample * chunk8)) ? 4 : 8;
-            B.sel_mode = 2;
+            sel_mode = 2;
             RB.width_hint = bulk; RB.hint_w = w; RB.hint_inc = inc;
-        }
-        if (bulk == 4) { B.out_list = c->d_ovf_list.p; B.out_count = c->d_ovf_count.p; }
-        else { B.out_list = c->d_ovf_list2.p; B.out_count = c->d_ovf_count.p + 1; }
-        const int64_t bulk_chunks = B.sel_mode == 2 ? nchunks - (nchunks + B.sel_mod - 1) / B.sel_mod : nchunks;
-        HIPC(c, launch_narrow(c->kmax, bulk, small_w, debug, B, c->num_cu, bulk_chunks, c->stream));
-        c->scan_stat[0] = bulk;
-        if (bulk == 4 || B.sel_mode == 2) {     // list 1 (4-bit hand-overs, the sample's included) -> 8-bit -> list 2
+            // the sample's own hand-overs now (list 1 -> 8-bit -> list 2 -> 16-bit), so that lists and counters are free for
+            // the bulk segments and no later pass touches rows of another segment
             ScanParams H = P;
             H.in_list = c->d_ovf_list.p; H.in_count = c->d_ovf_count.p;
-            H.out_list = c->d_ovf_list2.p; H.out_count = c->d_ovf_count.p + 1;
-            HIPC(c, launch_narrow(c->kmax, 8, small_w, debug, H, c->num_cu, n, c->stream));
+            H.out_list = c->d_ovf_list2.p; H.out_count = c->d_ovf_count.p + 1; H.queue = c->d_ovf_count.p + 3;
+            HIPC(c, launch_narrow(c->kmax, 8, small_w, false, H, c->num_cu, nsample * chunk8, c->stream));
+            ScanParams H2 = P;
+            H2.in_list = c->d_ovf_list2.p; H2.in_count = c->d_ovf_count.p + 1;
+            int g16 = int(std::min<int64_t>(n, int64_t(c->num_cu)));
+            if (g16 >= 8) g16 &= ~7;
+            HIPC(c, launch16(H2, g16, c->stream));
+            HIPC(c, hipMemcpyAsync(novf_sample, c->d_ovf_count.p, sizeof(novf_sample), hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 8 * sizeof(unsigned int), c->stream));
         }
-        // list 2 -> 16-bit counters, one window per workgroup at a time (a no-op when the list is empty)
-        P.in_list = c->d_ovf_list2.p; P.in_count = c->d_ovf_count.p + 1;
-        grid = int(std::min<int64_t>(n, int64_t(c->num_cu)));
-        if (grid >= 8) grid &= ~7;
-        if (k8) {
-            if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
-            else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
-            else if (its == 10) FRISK_LAUNCH(512, true, 10, false);
-            else if (its == 16) FRISK_LAUNCH(512, true, 16, false);
-            else FRISK_LAUNCH(1024, true, 0, false);
+        c->scan_stat[0] = bulk;
+        // Rows [r0, r1) of this scan on stream `st`: bulk launch, the two hand-over launches, the rows' scalar tail, and the
+        // rows to the host.  Segment `seg` has its own slice of the two lists and its own counters (0: [0], [1]; 1: [4], [5]);
+        // the sample's hand-overs (list 1 from entry 0, counter [0]) belong to segment 0.
+        auto run_rows = [&](int seg, int64_t r0, int64_t r1, hipStream_t st, bool fork_tail) -> int {
+            const int64_t m = r1 - r0;
+            ScanParams R = P;
+            R.c0 = P.c0 + r0; R.c1 = P.c0 + r1;
+            R.seq_index += r0; R.start += r0; R.stop += r0; R.status += r0; R.kld += r0; R.gc += r0; R.sw += r0; R.sg += r0;
+            if (rip) { R.pi += r0; R.si += r0; R.cri += r0; }
+            if (R.dbg_counts) R.dbg_counts += r0 * int64_t(c->nprof);
+            if (R.dbg_meta) R.dbg_meta += r0 * 3;
+            if (R.dbg_ivom) R.dbg_ivom += r0 * 2 * int64_t(nk);
+            unsigned int* cnt = c->d_ovf_count.p + 4 * seg;
+            int64_t* list1 = c->d_ovf_list.p + r0;
+            int64_t* list2 = c->d_ovf_list2.p + r0;
+            ScanParams B = R;                       // the bulk launch
+            B.chunk = int32_t(chunk8);
+            B.sel_mode = sel_mode;
+            if (bulk == 4) { B.out_list = list1; B.out_count = cnt; }
+            else { B.out_list = list2; B.out_count = cnt + 1; }
+            B.queue = cnt + 2;
+            const int64_t mchunks = (m + chunk8 - 1) / chunk8;
+            const int64_t bulk_chunks = sel_mode == 2 ? mchunks - (mchunks + B.sel_mod - 1) / B.sel_mod : mchunks;
+            HIPC(c, launch_narrow(c->kmax, bulk, small_w, debug, B, c->num_cu, bulk_chunks, st));
+            if (bulk == 4) {                        // list 1 (4-bit hand-overs) -> 8-bit -> list 2
+                ScanParams H = R;
+                H.in_list = list1; H.in_count = cnt;
+                H.out_list = list2; H.out_count = cnt + 1; H.queue = cnt + 3;
+                HIPC(c, launch_narrow(c->kmax, 8, small_w, debug, H, c->num_cu, m, st));
+            }
+            // list 2 -> 16-bit counters, one window per workgroup at a time (a no-op when the list is empty)
+            R.in_list = list2; R.in_count = cnt + 1;
+            int g16 = int(std::min<int64_t>(m, int64_t(c->num_cu)));
+            if (g16 >= 8) g16 &= ~7;
+            HIPC(c, launch16(R, g16, st));
+            if (fork_tail) {        // the tail segment starts here: beside this segment's scalar tail and its rows' way to the host
+                HIPC(c, hipEventRecord(c->ev_fork, st));
+                HIPC(c, hipStreamWaitEvent(c->tail_stream, c->ev_fork, 0));
+            }
+            finish_rows_kernel<<<grid_for(m, 256, 1 << 20), 256, 0, st>>>(m, R.status, R.kld, R.gc, R.sw, R.sg);
+            HIPC(c, hipGetLastError());
+            return FRISK_OK;
+        };
+        // The last sixteenth of a long scan goes to a second stream and starts when the kernels of the first fifteen are done:
+        // it runs while their rows travel to the host (16 MB per 410 k windows: 0.36 ms that used to follow the scan).  The
+        // cut is a multiple of 16 chunks: chunk numbering and the sample's stride stay aligned across it.
+        const int64_t unit = chunk8 * P.sel_mod;
+        int64_t cut = n;
+        if (!debug && !c->want_ivom && n >= 64 * unit && !tune_env("FRISK_ONE_SEGMENT"))
+            cut = (n / unit - std::max<int64_t>(1, n / unit / 16)) * unit;
+        rc = run_rows(0, 0, cut, c->stream, cut < n);
+        if (rc) return rc;
+        if (cut < n) {
+            rc = run_rows(1, cut, n, c->tail_stream, false);
+            if (rc) return rc;
+            HIPC(c, hipEventRecord(c->ev_tail_kernels, c->tail_stream));
+            rc = copy_rows(cut, n, c->tail_stream);
+            if (rc) return rc;
+            HIPC(c, hipEventRecord(c->ev_tail_done, c->tail_stream));
+            rc = copy_rows(0, cut, c->stream);
+            if (rc) return rc;
+            HIPC(c, hipStreamWaitEvent(c->stream, c->ev_tail_kernels, 0));
+            HIPC(c, hipEventRecord(c->ev1, c->stream));                     // every scan kernel of this call has finished
+            HIPC(c, hipStreamWaitEvent(c->stream, c->ev_tail_done, 0));
         } else {
-            if (debug) { if (its) FRISK_LAUNCH(512, false, 16, true); else FRISK_LAUNCH(1024, false, 0, true); }
-            else if (its == 4) FRISK_LAUNCH(512, false, 4, false);
-            else if (its == 10) FRISK_LAUNCH(512, false, 10, false);
-            else if (its == 16) FRISK_LAUNCH(512, false, 16, false);
-            else FRISK_LAUNCH(1024, false, 0, false);
+            HIPC(c, hipEventRecord(c->ev1, c->stream));
+            rc = copy_rows(0, n, c->stream);
+            if (rc) return rc;
         }
+        rows_sent = true;
+        c->scan_stat[3] = cut < n ? 2 : 1;
     } else if (k8) {
-        if (debug) { if (its) FRISK_LAUNCH(512, true, 16, true); else FRISK_LAUNCH(1024, true, 0, true); }
-        else if (its == 4) FRISK_LAUNCH(512, true, 4, false);
-        else if (its == 10) FRISK_LAUNCH(512, true, 10, false);
-        else if (its == 16) FRISK_LAUNCH(512, true, 16, false);
-        else FRISK_LAUNCH(1024, true, 0, false);
+        e = launch16(P, grid, c->stream);
     } else if (!debug && !force_one && c->plan_maxwin <= 5120 && L.total <= 80 * 1024) {
         // K <= 7: the tables of a window take < 60 KB, so TWO independent 256-thread workgroups fit a CU.  The two waves of
         // a SIMD then belong to different windows in different stages, and the LDS phases of one overlap the VALU phases of
@@ -1109,11 +1212,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         P.chunk = int32_t(std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(grid) * 8), 8)));
         if (c->plan_maxwin <= 2048) FRISK_LAUNCH(256, false, 8, false); else FRISK_LAUNCH(256, false, 20, false);
     } else {
-        if (debug) { if (its) FRISK_LAUNCH(512, false, 16, true); else FRISK_LAUNCH(1024, false, 0, true); }
-        else if (its == 4) FRISK_LAUNCH(512, false, 4, false);
-        else if (its == 10) FRISK_LAUNCH(512, false, 10, false);
-        else if (its == 16) FRISK_LAUNCH(512, false, 16, false);
-        else FRISK_LAUNCH(1024, false, 0, false);
+        e = launch16(P, grid, c->stream);
     }
 #undef FRISK_LAUNCH
     HIPC(c, e);
@@ -1136,35 +1235,24 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         d_stamps.release();
     }
 #endif
-#ifndef FRISK_STOP
-    if (c->plan_maxwin <= 65535 && c->kmax <= 8 && n > 0) {     // the LDS kernels leave the rows' scalar tail to one thread per row
-        finish_rows_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(n, c->o_status.p, c->o_kld.p, c->o_gc.p, c->o_sw.p,
-                                                                            c->o_sg.p);
-        HIPC(c, hipGetLastError());
-    }
-#endif
-    HIPC(c, hipEventRecord(c->ev1, c->stream));
-
-    HIPC(c, hipMemcpyAsync(seq_index, c->o_seq.p, N * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(start, c->o_start.p, N * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(stop, c->o_stop.p, N * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(status, c->o_status.p, N * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(kld, c->o_kld.p, N * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(gc, c->o_gc.p, N * 8, hipMemcpyDeviceToHost, c->stream));
-    if (rip) {
-        HIPC(c, hipMemcpyAsync(pi, c->o_pi.p, N * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipMemcpyAsync(si, c->o_si.p, N * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipMemcpyAsync(cri, c->o_cri.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!rows_sent) {
+        if (c->plan_maxwin <= 65535 && c->kmax <= 8 && n > 0) {     // the LDS kernels leave the rows' scalar tail to one thread per row
+            finish_rows_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(n, c->o_status.p, c->o_kld.p, c->o_gc.p, c->o_sw.p,
+                                                                                c->o_sg.p);
+            HIPC(c, hipGetLastError());
+        }
+        HIPC(c, hipEventRecord(c->ev1, c->stream));
+        rc = copy_rows(0, n, c->stream);
+        if (rc) return rc;
     }
     if (dbg_counts)
         HIPC(c, hipMemcpyAsync(dbg_counts, c->o_counts.p, N * size_t(c->nprof) * 4, hipMemcpyDeviceToHost, c->stream));
     if (dbg_meta) HIPC(c, hipMemcpyAsync(dbg_meta, c->o_meta.p, N * 3 * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->want_ivom) HIPC(c, hipMemcpyAsync(c->want_ivom, c->o_ivom.p, N * 2 * nk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    unsigned int novf[2] = {0, 0};
     if (narrow) HIPC(c, hipMemcpyAsync(novf, c->d_ovf_count.p, sizeof(novf), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    c->scan_stat[1] = novf[0];
-    c->scan_stat[2] = novf[1];
+    c->scan_stat[1] = novf[0] + novf[4] + novf_sample[0];
+    c->scan_stat[2] = novf[1] + novf[5] + novf_sample[1];
     if (c->b().tiled)               // descriptor index -> index of the scaffold in the FASTA
         for (size_t r = 0; r < N; ++r) seq_index[r] = c->b().tiles[size_t(seq_index[r])].scaf;
     float ms = 0;
@@ -1219,6 +1307,6 @@ char* frisk_format_rows(int64_t n, const char* const* names, const int32_t* seq_
 }
 void frisk_free(void* p) { std::free(p); }
 
-int64_t frisk_last_scan_stat(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 3) ? c->scan_stat[which] : -1; }
+int64_t frisk_last_scan_stat(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->scan_stat[which] : -1; }
 
 }  // extern "C"

@@ -228,6 +228,19 @@ __global__ __launch_bounds__(256) void marginalize_kernel(int64_t* __restrict__ 
     cnt[table_offset(kmin, x) + q] += up[0] + up[1] + up[2] + up[3];
 }
 
+// The same for all orders x_hi, x_hi-1, ..., kmin in ONE launch of one workgroup (x_hi <= 7: at most 16 K bins on the widest
+// level): below order 8 a launch per order is all launch latency (seven launches of ~2 us of work, ~7 us apart).
+__global__ __launch_bounds__(1024) void marginalize_low_kernel(int64_t* __restrict__ cnt, int kmin, int x_hi) {
+    for (int x = x_hi; x >= kmin; --x) {
+        const int64_t n = int64_t(1) << (2 * x);
+        int64_t* dst = cnt + table_offset(kmin, x);
+        const int64_t* up = cnt + table_offset(kmin, x + 1);
+        for (int64_t q = threadIdx.x; q < n; q += blockDim.x) dst[q] += up[4 * q] + up[4 * q + 1] + up[4 * q + 2] + up[4 * q + 3];
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // genome mode adds the reverse complement of every counted word (L350-351):
 // sym[c] = fwd[c] + fwd[rc(c)] - a palindromic word therefore counts twice per occurrence.
 __global__ __launch_bounds__(256) void symmetrize_kernel(const int64_t* __restrict__ fwd, int64_t* __restrict__ sym,

@@ -190,7 +190,19 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
         }
     };
-    for (int64_t q = v; q < nchunks; q += G) {
+    // Chunks are dealt by a global counter when the launcher provides one: a workgroup takes the next chunk when it is done
+    // with its last.  Chunks differ a lot in cost (windows that the N filter drops stop after stage 2), and with the static
+    // deal - chunk v, v + G, v + 2 G ... - the launch ended with 4 % of its time spent waiting for the unluckiest workgroups.
+    uint32_t* next_q = reinterpret_cast<uint32_t*>(scratch);         // (the waves' partial sums live here at the END of a window)
+    for (int64_t qs = v;; qs += G) {
+        int64_t q = qs;
+        if (P.queue) {
+            if (tid0 == 0) *next_q = atomicAdd(P.queue, 1u);
+            __syncthreads();
+            q = int64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(*next_q))));
+            __syncthreads();
+        }
+        if (q >= nchunks) break;
         int64_t qq = q;                                                  // chunk index inside [c0, c1)
         if (!listed && P.sel_mode == 1) qq = q * M;
         if (!listed && P.sel_mode == 2) qq = (q / (M - 1)) * M + 1 + q % (M - 1);

@@ -305,8 +305,8 @@ class Engine:
         return wi[:n], gi[:n]
 
     def scan_stat(self):
-        """(counter width of the bulk launch, windows handed 4->8 bit, windows handed on to 16 bit) of the last scan."""
-        return tuple(int(self._lib.frisk_last_scan_stat(self._ctx, i)) for i in range(3))
+        """(counter width of the bulk launch, windows handed 4->8 bit, windows handed on to 16 bit, row segments) of the last scan."""
+        return tuple(int(self._lib.frisk_last_scan_stat(self._ctx, i)) for i in range(4))
 
     def kernel_ms(self, which=0):
         return float(self._lib.frisk_last_kernel_ms(self._ctx, which))

@@ -163,7 +163,8 @@ int frisk_scan_ivom(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int6
 /* Diagnostics of the most recent frisk_scan (results never depend on them).  The default K = 8 kernel counts max-mers in
  * 4- or 8-bit counters and hands a window with a more frequent max-mer (low-complexity sequence) to the next wider form:
  * which = 0: counter width of the bulk launch (4 or 8; 16 = the narrow kernel was not used),
- *         1: windows handed from 4-bit to 8-bit counters,   2: windows handed on to 16-bit counters. */
+ *         1: windows handed from 4-bit to 8-bit counters,   2: windows handed on to 16-bit counters,
+ *         3: row segments (2: the last sixteenth of a long scan ran on a second stream while the rows of the rest went to the host). */
 int64_t frisk_last_scan_stat(const frisk_ctx* ctx, int which);
 
 /* The rows of the score table as text, exactly as the reference's scan loop writes them (L1487-1494): tab-separated

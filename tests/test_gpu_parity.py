@@ -518,6 +518,7 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
         sym, tl, ex, nn = e.profile_get()
         res = e.scan(5000, 1000, rip=True)
         stat = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
+        segments = int(_ffi.lib().frisk_last_scan_stat(e._ctx, 3))
         sub = e.scan(5000, 1000, rip=True, c0=1234, c1=4321)                   # another range: another sample, other widths
         few = e.scan(5000, 1000, rip=True, c0=700, c1=1000)                     # same batch and geometry: the first sample's choice holds
         stat_few = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
@@ -527,6 +528,7 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
         stat_other = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
     assert stat[0] == expect_bulk, stat
     assert stat[1] > 50 and stat[2] > 5, stat                                  # both hand-over lists were used
+    assert segments == 2                                                       # ... by both row segments of the long scan (two streams)
     assert stat_few[0] == expect_bulk, stat_few
     for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):        # same bits whichever form scored the window
         assert np.array_equal(getattr(sub, f), getattr(res, f)[1234:4321], equal_nan=True), f
