@@ -103,7 +103,7 @@ struct frisk_ctx {
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
     DevBuf<double> d_ig, d_logtab, d_logtab64, d_logtab32, d_rctab;
     DevBuf<int64_t> d_ovf_list, d_ovf_list2;   // windows handed from 4-bit to 8-bit counters, and from there to the 16-bit form
-    DevBuf<unsigned int> d_ovf_count;          // [0], [1]: their numbers, [2], [3]: chunk counters of the bulk and 8-bit launches; [4..7]: the same for the scan's tail segment
+    DevBuf<unsigned int> d_ovf_count;          // per row segment 32 counters: [0], [1] the lists' lengths, [8..15] the bulk launch's chunk queues, [16] the 8-bit launch's
     int64_t scan_stat[4] = {0, 0, 0, 0};       // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16, row segments
     DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
     DevBuf<int64_t> d_meta;          // {totalLen, exMax, nnTotal} of the finalised profile, on the device
@@ -431,7 +431,7 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
         for (int i = 1; i < 256; ++i) rc[i] = 1.0 / double(i);
         HIPC(c, c->d_rctab.reserve(256));
         HIPC(c, hipMemcpyAsync(c->d_rctab.p, rc, sizeof(rc), hipMemcpyHostToDevice, c->stream));
-        HIPC(c, c->d_ovf_count.reserve(8));
+        HIPC(c, c->d_ovf_count.reserve(64));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -988,7 +988,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
     P.stamps = nullptr;
     P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
-    P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr;
+    P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr; P.queue_n = 1;
     c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0; c->scan_stat[3] = 1;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
@@ -1064,7 +1064,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         return FRISK_OK;
     };
     bool rows_sent = false;                 // the narrow-counter path finishes and ships its rows itself, in two segments
-    unsigned int novf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, novf_sample[2] = {0, 0};
+    unsigned int novf[34] = {0}, novf_sample[2] = {0, 0};
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e = hipSuccess;
     if (c->plan_maxwin > 65535 || c->kmax > 8) {
@@ -1090,11 +1090,13 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         // results do not depend on the choice, on the grid, or on the candidate range.
         HIPC(c, c->d_ovf_list.reserve(N));
         HIPC(c, c->d_ovf_list2.reserve(N));
-        HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 8 * sizeof(unsigned int), c->stream));
+        HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 64 * sizeof(unsigned int), c->stream));
         const bool small_w = w <= 2048;
         int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), 8));
         if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk8 = std::max<int64_t>(1, std::atoll(ev));
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
+        // chunks dealt by counters (scan8_kernel.h) where a chunk is long enough to pay for the exchange: a short scan keeps the static deal
+        const bool dealt = chunk8 >= 4;
         int bulk = (width == 4 && narrow8) ? 4 : 8;
         int sel_mode = 0;
         frisk_ctx::Batch& RB = c->b();
@@ -1104,7 +1106,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         else if (width == 0 && !debug && nchunks >= 64 * P.sel_mod) {
             ScanParams S = P;                   // the sample
             S.chunk = int32_t(chunk8);
-            S.sel_mode = 1; S.out_list = c->d_ovf_list.p; S.out_count = c->d_ovf_count.p; S.queue = c->d_ovf_count.p + 2;
+            S.sel_mode = 1; S.out_list = c->d_ovf_list.p; S.out_count = c->d_ovf_count.p;
+            if (dealt) { S.queue = c->d_ovf_count.p + 8; S.queue_n = 8; }
             const int64_t nsample = (nchunks + S.sel_mod - 1) / S.sel_mod;
             HIPC(c, launch_narrow(c->kmax, 4, small_w, false, S, c->num_cu, nsample, c->stream, true));
             unsigned int handed = 0;
@@ -1119,7 +1122,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
             // the bulk segments and no later pass touches rows of another segment
             ScanParams H = P;
             H.in_list = c->d_ovf_list.p; H.in_count = c->d_ovf_count.p;
-            H.out_list = c->d_ovf_list2.p; H.out_count = c->d_ovf_count.p + 1; H.queue = c->d_ovf_count.p + 3;
+            H.out_list = c->d_ovf_list2.p; H.out_count = c->d_ovf_count.p + 1;
+            if (dealt) H.queue = c->d_ovf_count.p + 16;
             HIPC(c, launch_narrow(c->kmax, 8, small_w, false, H, c->num_cu, nsample * chunk8, c->stream));
             ScanParams H2 = P;
             H2.in_list = c->d_ovf_list2.p; H2.in_count = c->d_ovf_count.p + 1;
@@ -1127,7 +1131,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
             if (g16 >= 8) g16 &= ~7;
             HIPC(c, launch16(H2, g16, c->stream));
             HIPC(c, hipMemcpyAsync(novf_sample, c->d_ovf_count.p, sizeof(novf_sample), hipMemcpyDeviceToHost, c->stream));
-            HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 8 * sizeof(unsigned int), c->stream));
+            HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 64 * sizeof(unsigned int), c->stream));
         }
         c->scan_stat[0] = bulk;
         // Rows [r0, r1) of this scan on stream `st`: bulk launch, the two hand-over launches, the rows' scalar tail, and the
@@ -1142,7 +1146,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
             if (R.dbg_counts) R.dbg_counts += r0 * int64_t(c->nprof);
             if (R.dbg_meta) R.dbg_meta += r0 * 3;
             if (R.dbg_ivom) R.dbg_ivom += r0 * 2 * int64_t(nk);
-            unsigned int* cnt = c->d_ovf_count.p + 4 * seg;
+            unsigned int* cnt = c->d_ovf_count.p + 32 * seg;
             int64_t* list1 = c->d_ovf_list.p + r0;
             int64_t* list2 = c->d_ovf_list2.p + r0;
             ScanParams B = R;                       // the bulk launch
@@ -1150,14 +1154,15 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
             B.sel_mode = sel_mode;
             if (bulk == 4) { B.out_list = list1; B.out_count = cnt; }
             else { B.out_list = list2; B.out_count = cnt + 1; }
-            B.queue = cnt + 2;
+            if (dealt) { B.queue = cnt + 8; B.queue_n = 8; }
             const int64_t mchunks = (m + chunk8 - 1) / chunk8;
             const int64_t bulk_chunks = sel_mode == 2 ? mchunks - (mchunks + B.sel_mod - 1) / B.sel_mod : mchunks;
             HIPC(c, launch_narrow(c->kmax, bulk, small_w, debug, B, c->num_cu, bulk_chunks, st));
             if (bulk == 4) {                        // list 1 (4-bit hand-overs) -> 8-bit -> list 2
                 ScanParams H = R;
                 H.in_list = list1; H.in_count = cnt;
-                H.out_list = list2; H.out_count = cnt + 1; H.queue = cnt + 3;
+                H.out_list = list2; H.out_count = cnt + 1;
+                if (dealt) H.queue = cnt + 16;
                 HIPC(c, launch_narrow(c->kmax, 8, small_w, debug, H, c->num_cu, m, st));
             }
             // list 2 -> 16-bit counters, one window per workgroup at a time (a no-op when the list is empty)
@@ -1178,7 +1183,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         // cut is a multiple of 16 chunks: chunk numbering and the sample's stride stay aligned across it.
         const int64_t unit = chunk8 * P.sel_mod;
         int64_t cut = n;
-        if (!debug && !c->want_ivom && n >= 64 * unit && !tune_env("FRISK_ONE_SEGMENT"))
+        // (worth a second launch only when the rows' way to the host is long against a launch: 40 B x 128 K rows ~ 0.1 ms)
+        if (!debug && !c->want_ivom && n >= (int64_t(1) << 17) && n >= 64 * unit && !tune_env("FRISK_ONE_SEGMENT"))
             cut = (n / unit - std::max<int64_t>(1, n / unit / 16)) * unit;
         rc = run_rows(0, 0, cut, c->stream, cut < n);
         if (rc) return rc;
@@ -1251,8 +1257,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     if (c->want_ivom) HIPC(c, hipMemcpyAsync(c->want_ivom, c->o_ivom.p, N * 2 * nk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (narrow) HIPC(c, hipMemcpyAsync(novf, c->d_ovf_count.p, sizeof(novf), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    c->scan_stat[1] = novf[0] + novf[4] + novf_sample[0];
-    c->scan_stat[2] = novf[1] + novf[5] + novf_sample[1];
+    c->scan_stat[1] = novf[0] + novf[32] + novf_sample[0];
+    c->scan_stat[2] = novf[1] + novf[33] + novf_sample[1];
     if (c->b().tiled)               // descriptor index -> index of the scaffold in the FASTA
         for (size_t r = 0; r < N; ++r) seq_index[r] = c->b().tiles[size_t(seq_index[r])].scaf;
     float ms = 0;

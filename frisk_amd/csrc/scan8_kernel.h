@@ -190,17 +190,38 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
         }
     };
-    // Chunks are dealt by a global counter when the launcher provides one: a workgroup takes the next chunk when it is done
-    // with its last.  Chunks differ a lot in cost (windows that the N filter drops stop after stage 2), and with the static
-    // deal - chunk v, v + G, v + 2 G ... - the launch ended with 4 % of its time spent waiting for the unluckiest workgroups.
+    // Chunks are dealt by counters when the launcher provides them: a workgroup takes the next chunk when it is done with
+    // its last.  Chunks differ a lot in cost (windows that the N filter drops stop after stage 2), and with the static deal -
+    // chunk v, v + G, v + 2 G ... - a launch ended with 8 % of its time spent waiting for the unluckiest workgroups.  One
+    // counter per XCD (blocks b and b + 8 share one), each over a contiguous eighth of the chunks: consecutive chunks - whose
+    // windows overlap - go through the same L2, as with the static deal; a workgroup whose XCD has run dry takes from the
+    // next one's.  Thread 0 asks for the chunk after this one before it starts on this one, so the round trip of the atomic
+    // hides behind a chunk's work.
     uint32_t* next_q = reinterpret_cast<uint32_t*>(scratch);         // (the waves' partial sums live here at the END of a window)
+    const bool dealt = P.queue != nullptr;
+    const uint32_t NQ = dealt ? uint32_t(P.queue_n) : 1u;
+    const uint32_t myq = blockIdx.x % NQ;
+    uint32_t dry = 0, ahead = 0;                                     // (thread 0) queues found empty so far; the index asked for ahead
+    if (dealt && tid0 == 0) ahead = atomicAdd(&P.queue[myq], 1u);
     for (int64_t qs = v;; qs += G) {
         int64_t q = qs;
-        if (P.queue) {
-            if (tid0 == 0) *next_q = atomicAdd(P.queue, 1u);
+        if (dealt) {
+            if (tid0 == 0) {
+                uint32_t got = 0xFFFFFFFFu;
+                while (dry < NQ) {
+                    const uint32_t j = (myq + dry) % NQ;
+                    const int64_t b = nchunks * j / NQ, len = nchunks * (j + 1) / NQ - b;
+                    if (int64_t(ahead) < len) { got = uint32_t(b + ahead); break; }
+                    if (++dry < NQ) ahead = atomicAdd(&P.queue[(myq + dry) % NQ], 1u);
+                }
+                *next_q = got;
+                if (got != 0xFFFFFFFFu) ahead = atomicAdd(&P.queue[(myq + dry) % NQ], 1u);
+            }
             __syncthreads();
-            q = int64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(*next_q))));
+            const uint32_t got = uint32_t(__builtin_amdgcn_readfirstlane(int(*next_q)));
             __syncthreads();
+            if (got == 0xFFFFFFFFu) break;
+            q = int64_t(got);
         }
         if (q >= nchunks) break;
         int64_t qq = q;                                                  // chunk index inside [c0, c1)

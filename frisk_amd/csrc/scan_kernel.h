@@ -83,7 +83,8 @@ struct ScanParams {
     int64_t* out_list;            // scan8_kernel appends the windows it could not hold ...
     unsigned int* out_count;      // ... and counts them
     int32_t sel_mode, sel_mod;    // scan8_kernel, range mode: 0 all chunks, 1 every sel_mod-th chunk, 2 all the others
-    unsigned int* queue;          // scan8_kernel: != nullptr: chunks are dealt by this counter (zero at launch) instead of by block index
+    unsigned int* queue;          // scan8_kernel: != nullptr: chunks are dealt by these counters (zero at launch) instead of by block index:
+    int32_t queue_n;              // ... queue_n (1 or 8) of them, one per XCD, each over a contiguous share of the chunks
 };
 
 #define ROW_KEPT 1u

@@ -493,15 +493,10 @@ def test_windows_beyond_lds_counters_against_c_oracle(kmin, kmax, w, inc, scaffo
     assert np.array_equal(res.kld, res2.kld, equal_nan=True) and np.array_equal(res.status, res2.status)
 
 
-@pytest.mark.parametrize("every,expect_bulk", [(60000, 4), (9000, 8)])
-def test_adaptive_counter_width_and_handover(every, expect_bulk):
-    """The default K = 8 kernel counts max-mers in 4- or 8-bit counters (scan8_kernel.h) and hands windows with a more
-    frequent max-mer to the next wider form: 4-bit -> 8-bit -> 16-bit.  A 12 Mb genome with microsatellites and poly-A
-    runs (a few of them longer than 8-bit counters hold) sprinkled in: every row must still equal the compiled oracle's,
-    the hand-over lists must have been used, and the sample must have picked the expected width for the bulk."""
-    from oracle import frisk_oracle_c as OC
-    from frisk_amd import _ffi, synth
-    n = 12_000_000
+def _genome_with_repeats(n, every):
+    """One synthetic scaffold with microsatellites and poly-A runs sprinkled in, one about every `every` bases - a few of
+    them longer than 8-bit counters hold."""
+    from frisk_amd import synth
     s = np.frombuffer(synth.scaffold(n, 77, 0, island_frac=0.05, n_frac=0.01, lower_frac=0.01), dtype=np.uint8).copy()
     rng = np.random.default_rng(every)
     units = [b"A", b"T", b"CA", b"TG", b"AAT", b"GATA", b"TTAGGG"]
@@ -511,14 +506,24 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
         ln = int(rng.choice([24, 40, 60, 90, 300, 700]))                       # 300+: wraps 8-bit counters as well
         rep = (u * (ln // len(u) + 1))[:ln]
         s[a:a + ln] = np.frombuffer(rep, dtype=np.uint8)
-    seqs = [s.tobytes()]
+    return [s.tobytes()]
+
+
+@pytest.mark.parametrize("every,expect_bulk", [(60000, 4), (9000, 8)])
+def test_adaptive_counter_width_and_handover(every, expect_bulk):
+    """The default K = 8 kernel counts max-mers in 4- or 8-bit counters (scan8_kernel.h) and hands windows with a more
+    frequent max-mer to the next wider form: 4-bit -> 8-bit -> 16-bit.  A 12 Mb genome with microsatellites and poly-A
+    runs (a few of them longer than 8-bit counters hold) sprinkled in: every row must still equal the compiled oracle's,
+    the hand-over lists must have been used, and the sample must have picked the expected width for the bulk."""
+    from oracle import frisk_oracle_c as OC
+    from frisk_amd import _ffi
+    seqs = _genome_with_repeats(12_000_000, every)
     with make_engine(1, 8) as e:
         e.load(seqs)
         e.profile_reset(); e.profile_add(); e.profile_finalize()
         sym, tl, ex, nn = e.profile_get()
         res = e.scan(5000, 1000, rip=True)
         stat = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
-        segments = int(_ffi.lib().frisk_last_scan_stat(e._ctx, 3))
         sub = e.scan(5000, 1000, rip=True, c0=1234, c1=4321)                   # another range: another sample, other widths
         few = e.scan(5000, 1000, rip=True, c0=700, c1=1000)                     # same batch and geometry: the first sample's choice holds
         stat_few = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
@@ -528,7 +533,6 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
         stat_other = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
     assert stat[0] == expect_bulk, stat
     assert stat[1] > 50 and stat[2] > 5, stat                                  # both hand-over lists were used
-    assert segments == 2                                                       # ... by both row segments of the long scan (two streams)
     assert stat_few[0] == expect_bulk, stat_few
     for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):        # same bits whichever form scored the window
         assert np.array_equal(getattr(sub, f), getattr(res, f)[1234:4321], equal_nan=True), f
@@ -546,6 +550,42 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
     for col in ("pi", "si", "cri"):
         assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
     assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
+
+
+def test_long_scan_in_two_row_segments():
+    """A scan of more than 2^17 candidates runs its last sixteenth as a second launch on a second stream while the rows of
+    the first fifteen go to the host; chunks are dealt by per-XCD counters.  133 k windows over a genome with repeats that
+    wrap 4- and 8-bit counters: both segments hand windows on, the rows equal those of four shorter scans (one segment
+    each) bit for bit, and the rows on both sides of the cut equal the compiled oracle's."""
+    from oracle import frisk_oracle_c as OC
+    seqs = _genome_with_repeats(12_000_000, 60000)
+    w, inc = 5000, 90
+    with make_engine(1, 8) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        sym, tl, ex, nn = e.profile_get()
+        res = e.scan(w, inc)
+        stat = e.scan_stat()
+        n = res.n_candidates
+        assert n > (1 << 17) and stat[3] == 2 and stat[1] > 100 and stat[2] > 10, (n, stat)
+        cuts = [0, n // 4, n // 2, n - n // 4, n]
+        for a, b in zip(cuts, cuts[1:]):
+            part = e.scan(w, inc, c0=a, c1=b)
+            assert e.scan_stat()[3] == 1
+            for f in ("seq_index", "start", "stop", "status", "kld", "gc"):
+                assert np.array_equal(getattr(part, f), getattr(res, f)[a:b], equal_nan=True), (f, a, b)
+    S = OC.Seqs(seqs)
+    osym, ometa = OC.genome_profile(S, 1, 8)
+    ig = OC.genome_ivom(osym, ometa, 1, 8)
+    unit = 8 * 16
+    cut = (n // unit - max(1, n // unit // 16)) * unit                      # where frisk_scan cuts (chunks of 8, stride 16)
+    for a, b in ((cut - 1500, cut + 1500), (n - 2000, n), (0, 2000)):
+        exp = OC.scan(S, ig, 1, 8, w, inc, cand=(a, b))
+        k = a + np.nonzero(res.kept[a:b])[0]
+        assert len(k) == len(exp["kld"])
+        assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"])
+        assert np.array_equal(res.gc[k], exp["gc"])
+        assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
 
 
 @pytest.mark.parametrize("w,inc,scaffolds_all,kmin,kmax", [(5000, 1000, False, 1, 8), (2000, 2500, True, 1, 8), (3000, 700, True, 2, 6),
