@@ -11,7 +11,8 @@
 //               else is counted there: no lower-order update, no election of representatives.
 //   * stage 2   the (K-3)-mer counts are the sums of 64 neighbouring counters: every thread sums whole 16-byte reads
 //               (v_sad_u8 / v_dot8_u32_u4), the read order rotated per lane (conflict-free); the orders below follow
-//               inside a wave by DPP sums.  The grand total of the table must equal the number of max-mer positions;
+//               inside a wave by DPP sums (K = 7, 8: as the first lines of stage 3, where thread t holds the 4-mer t -
+//               no barrier and no LDS round trip of their own).  The grand total of the table must equal the number of max-mer positions;
 //               a counter that wrapped (a max-mer occurring >= 2^BITS times: poly-A, microsatellites) breaks that
 //               equality, and the window is handed to the next wider form through a device-side list: 4-bit ->
 //               8-bit -> scan_kernel.h's 16-bit form (later launches on the same stream).
@@ -25,6 +26,8 @@
 //               summation that the election of representatives by atomic arrival order forced on scan_kernel.h (6 FP64
 //               instructions per term there, 1 multiply + 1 add here).  Positions that start no max-mer score a
 //               stand-in (a real max-mer of the window) with weight 0: no masks.
+//   * work      chunks of 8 consecutive windows, dealt by one counter per XCD (a workgroup takes the next chunk when it is
+//               done with its last; neighbouring chunks stay on one L2; an XCD that has run dry takes from the next one).
 // Windows up to NT*ITS bases, kmin <= K-3 (the shared prefix level); everything else stays on scan_kernel.h.
 // Measurements, the adaptive choice between 4 and 8 bits, and what was tried and dropped: DESIGN.md section 3.3.
 #pragma once
