@@ -767,7 +767,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #ifdef FRISK8_S4_GROUP
             constexpr int GR = FRISK8_S4_GROUP;
 #else
-            constexpr int GR = K == 8 ? 2 : 1;
+            constexpr int GR = (K == 8 && BITS == 4) ? 2 : 1;       // (8-bit form at K = 8: groups of one are 2..3 % ahead)
 #endif
 #ifdef FRISK8_ROLLED
             constexpr bool ROLLED = FRISK8_ROLLED != 0;
