@@ -120,6 +120,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     // the order-K table is cleared whole when that takes no more stores per thread than a lane has positions (measured: 64 KiB
     // for windows of 2000 bases is the one case where every position clearing its own dword is cheaper)
     constexpr bool CLEAR_ALL = L::t8_bytes / 16 / NT <= uint32_t(ITS);
+    // K = 7, 8: thread t sums the table below ITS OWN (K-3)-mers (the 4-mer t / its four 5-mers), so that stage 2 runs inside stage 3: no
+    // barrier and no LDS round trip between the table sums and the prefix tables made from them
+    constexpr bool FUSED = (KMAX >= 7 && NT == 256);                 // (K = 7: the 64 counters below the 4-mer t itself)
     __shared__ __attribute__((aligned(16))) unsigned char lds[L::total];
     const int tid0 = threadIdx.x;
     const int kmin0 = P.kmin;
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 
             // ---- stage 2: C_5[q] = D_5[q] + (sum of the 64 order-8 counters below q); grand total for the overflow check
             const uint32_t o5 = uint32_t(table_offset(kmin, LVL));         // the small tables' top order: K-3
-            {
+            if constexpr (!FUSED) {
                 uint32_t tot = 0;
                 for (uint32_t q5 = tid; q5 < NL; q5 += NT) {
                     uint32_t s = 0;
@@ -427,8 +430,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 }
                 tot = wave_sum_u32(tot);
                 if (lane == 0 && tot) atomicAdd(&misc[M8_TSUM], tot);
+                __syncthreads();
             }
-            __syncthreads();
             STAMP(3)
             // The orders below follow inside a wave, no LDS round trip between the levels.  LVL >= 4 (K = 7, 8): as part of
             // stage 3, where thread t holds the 4-mer t anyway.  LVL = 3 (K = 6): here - one wave, lane l = the 3-mer l.
@@ -458,7 +461,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             uint32_t status = (jump ? ROW_JUMPBACK : 0u);
             const uint32_t nvalid_top = uni(misc[M_NVALID]);
             const int n_orph = int(uni(misc[M_NORPH]));
-            const bool wrapped = uni(misc[M8_TSUM]) != nvalid_top || n_orph > FRISK8_ORPH_CAP;
+            // (fused form: the table's total is not known yet - that half of the test follows stage 3)
+            const bool wrapped = (!FUSED && uni(misc[M8_TSUM]) != nvalid_top) || n_orph > FRISK8_ORPH_CAP;
             const uint32_t safe_code = uni(misc[M8_SAFE]);
 
             auto zero_own = [&]() {             // every max-mer position clears its dword (all reads are behind a barrier)
@@ -466,24 +470,27 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 for (int it = 0; it < ITS; ++it)
                     if (fullm & (0x80000000u >> it)) t8[code_at(it) >> SHW] = 0u;
             };
-            if (wrapped || !keep) {
-                if (wrapped || CLEAR_ALL) clear_t8(); else zero_own();
+            // a counter wrapped, or too many orphans: the next wider form (8-bit, then scan_kernel.h's 16-bit) redoes this window
+            // from scratch
+            auto hand_over = [&]() {
+                clear_t8();
+                clear_small();
+                if (tid == 0) { const unsigned int slot = atomicAdd(P.out_count, 1u); P.out_list[slot] = cand; }
+                __syncthreads();
+            };
+            if (wrapped) { hand_over(); continue; }
+            if (!keep) {
+                // dropped by the N filter (the composition comes from popcounts of stage 1: reliable whatever the counters did)
+                if (CLEAR_ALL) clear_t8(); else zero_own();
                 clear_small();
                 if (tid == 0) {
-                    if (wrapped) {
-                        // a counter wrapped (every sum above is then unreliable, the N filter's included), or too many
-                        // orphans: the next wider form (8-bit, then scan_kernel.h's 16-bit) redoes this window from scratch
-                        const unsigned int slot = atomicAdd(P.out_count, 1u);
-                        P.out_list[slot] = cand;
-                    } else {
-                        P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop;
-                        P.status[row] = status;
-                        const double qnan = __longlong_as_double(0x7FF8000000000000LL);
-                        P.kld[row] = qnan; P.gc[row] = qnan;
-                        if (P.flags & 1u) { P.pi[row] = qnan; P.si[row] = qnan; P.cri[row] = qnan; }
-                        if (DEBUG && P.dbg_meta) {      // (dropped rows are not compared; keep the dump well defined)
-                            P.dbg_meta[row * 3 + 0] = n; P.dbg_meta[row * 3 + 1] = 0; P.dbg_meta[row * 3 + 2] = nn;
-                        }
+                    P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop;
+                    P.status[row] = status;
+                    const double qnan = __longlong_as_double(0x7FF8000000000000LL);
+                    P.kld[row] = qnan; P.gc[row] = qnan;
+                    if (P.flags & 1u) { P.pi[row] = qnan; P.si[row] = qnan; P.cri[row] = qnan; }
+                    if (DEBUG && P.dbg_meta) {      // (dropped rows are not compared; keep the dump well defined)
+                        P.dbg_meta[row * 3 + 0] = n; P.dbg_meta[row * 3 + 1] = 0; P.dbg_meta[row * 3 + 2] = nn;
                     }
                 }
                 __syncthreads();
@@ -596,14 +603,66 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     // back to the small tables (RIP indices, debug dump) and, from registers, into the prefix sums.
                     static_assert(NT == 256, "thread t <-> 4-mer t");
                     const uint32_t q4 = uint32_t(tid);
-                    uint32_t c5[4] = {0u, 0u, 0u, 0u};
+                    // c5[m] = the count of the 5-mer 4 q4 + j5[m] (K = 8).  Fused form: the sums of the 64 order-8 counters below each,
+                    // read here - thread t owns 128 (256) contiguous table bytes; which 5-mer comes first and which 16 bytes of it
+                    // rotate with the lane, so that the eight lanes of a bank group never meet (a b128 read takes eight passes anyway)
+                    uint32_t c5[4] = {0u, 0u, 0u, 0u}, j5[4] = {0u, 1u, 2u, 3u};
                     if constexpr (LV == 5) {
-                        const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ox[5] + 4 * q4);
-                        c5[0] = ch.x & 0xFFFFu; c5[1] = ch.x >> 16; c5[2] = ch.y & 0xFFFFu; c5[3] = ch.y >> 16;
+                        const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ox[5] + 4 * q4);     // D_5 (fused) or C_5, four u16
+                        if constexpr (FUSED) {
+                            const uint64_t d64 = (uint64_t(ch.y) << 32) | ch.x;
+                            const unsigned char* mine = t8b + q4 * (BITS == 8 ? 256u : 128u);
+                            uint32_t tot = 0;
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                const uint32_t j = (uint32_t(m) + uint32_t(tid)) & 3u;
+                                uint32_t sm = 0;
+                                if (BITS == 8) {
+#pragma unroll
+                                    for (int h = 0; h < 4; ++h) {
+                                        const uint32_t hh = (uint32_t(h) + (uint32_t(tid) >> 1)) & 3u;
+                                        const uint4 x = *reinterpret_cast<const uint4*>(mine + j * 64u + hh * 16u);
+                                        sm = __builtin_amdgcn_sad_u8(x.x, 0u, sm); sm = __builtin_amdgcn_sad_u8(x.y, 0u, sm);
+                                        sm = __builtin_amdgcn_sad_u8(x.z, 0u, sm); sm = __builtin_amdgcn_sad_u8(x.w, 0u, sm);
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        const uint32_t hh = (uint32_t(h) + (uint32_t(tid) >> 2)) & 1u;
+                                        const uint4 x = *reinterpret_cast<const uint4*>(mine + j * 32u + hh * 16u);
+                                        sm = __builtin_amdgcn_udot8(x.x, 0x11111111u, sm, false); sm = __builtin_amdgcn_udot8(x.y, 0x11111111u, sm, false);
+                                        sm = __builtin_amdgcn_udot8(x.z, 0x11111111u, sm, false); sm = __builtin_amdgcn_udot8(x.w, 0x11111111u, sm, false);
+                                    }
+                                }
+                                tot += sm;
+                                j5[m] = j;
+                                c5[m] = sm + (uint32_t(d64 >> (16u * j)) & 0xFFFFu);
+                                if (DEBUG) small16[ox[5] + 4 * q4 + j] = uint16_t(c5[m]);       // (only the dump reads C_5 again)
+                            }
+                            // the table's grand total, for the overflow test behind this stage's barrier
+                            tot = wave_sum_u32(tot);
+                            if (lane == 0 && tot) atomicAdd(&misc[M8_TSUM], tot);
+                        } else {
+                            c5[0] = ch.x & 0xFFFFu; c5[1] = ch.x >> 16; c5[2] = ch.y & 0xFFFFu; c5[3] = ch.y >> 16;
+                        }
                     }
                     uint32_t cx[5] = {0u, 0u, 0u, 0u, 0u};
+                    uint32_t below4 = 0;                // K = 7, fused form: the 64 order-7 counters (bytes) below the 4-mer
+                    if constexpr (LV == 4 && FUSED) {
+                        const unsigned char* mine = t8b + q4 * 64u;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const uint32_t hh = (uint32_t(h) + (uint32_t(tid) >> 1)) & 3u;
+                            const uint4 x = *reinterpret_cast<const uint4*>(mine + hh * 16u);
+                            below4 = __builtin_amdgcn_sad_u8(x.x, 0u, below4); below4 = __builtin_amdgcn_sad_u8(x.y, 0u, below4);
+                            below4 = __builtin_amdgcn_sad_u8(x.z, 0u, below4); below4 = __builtin_amdgcn_sad_u8(x.w, 0u, below4);
+                        }
+                        const uint32_t tot = wave_sum_u32(below4);
+                        if (lane == 0 && tot) atomicAdd(&misc[M8_TSUM], tot);
+                    }
                     if (kmin <= 4) {
-                        cx[4] = small16[ox[4] + q4];
+                        cx[4] = small16[ox[4] + q4] + below4;
+                        if constexpr (LV == 4 && FUSED) small16[ox[4] + q4] = uint16_t(cx[4]);
                         if constexpr (LV == 5) {
                             cx[4] += c5[0] + c5[1] + c5[2] + c5[3];
                             small16[ox[4] + q4] = uint16_t(cx[4]);
@@ -647,12 +706,17 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                             W5[m] = W4 + ((c5[m] & wm[5]) << 10);
                             A5[m] = __builtin_fma(cd * cd, rx[5], A4);
                         }
-                        auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
-                        auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
-                        uint4* out = reinterpret_cast<uint4*>(pre + 4 * q4);        // four entries = 48 bytes, 16-byte aligned
-                        out[0] = make_uint4(lo(A5[0]), hi(A5[0]), W5[0], lo(A5[1]));
-                        out[1] = make_uint4(hi(A5[1]), W5[1], lo(A5[2]), hi(A5[2]));
-                        out[2] = make_uint4(W5[2], lo(A5[3]), hi(A5[3]), W5[3]);
+                        if constexpr (FUSED) {          // (the four entries in the lane's rotated order)
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) { Pre8* e = pre + 4 * q4 + j5[m]; e->A = A5[m]; e->W = W5[m]; }
+                        } else {
+                            auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
+                            auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
+                            uint4* out = reinterpret_cast<uint4*>(pre + 4 * q4);        // four entries = 48 bytes, 16-byte aligned
+                            out[0] = make_uint4(lo(A5[0]), hi(A5[0]), W5[0], lo(A5[1]));
+                            out[1] = make_uint4(hi(A5[1]), W5[1], lo(A5[2]), hi(A5[2]));
+                            out[2] = make_uint4(W5[2], lo(A5[3]), hi(A5[3]), W5[3]);
+                        }
                     }
                 } else {
 #pragma unroll 2
@@ -675,6 +739,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             __syncthreads();
             STAMP(5)
+            if constexpr (FUSED) {          // the table's total against the number of max-mer positions: a counter wrapped
+                if (uni(misc[M8_TSUM]) != nvalid_top) { hand_over(); continue; }
+            }
 
             if (DEBUG && P.dbg_counts) {
                 uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
