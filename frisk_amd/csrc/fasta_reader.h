@@ -25,13 +25,29 @@
 namespace frisk_fasta {
 
 // std::vector<uint8_t> whose resize() does not zero the new bytes (they are all overwritten, by several threads)
+// Large blocks (the sequence of a multi-gigabase FASTA) come straight from mmap with transparent huge pages asked for: 2 MB
+// pages take the first-touch faults of the placing threads and the unmapping at the end from 800 k page operations per 3 GB
+// (0.2 s of unmapping alone, and the mm lock held against every other thread) to 1 600.
 template <class T>
 struct NoInitAlloc : std::allocator<T> {
+    static constexpr size_t BIG = size_t(64) << 20, HUGE_PAGE = size_t(2) << 20;
     template <class U> struct rebind { using other = NoInitAlloc<U>; };
     template <class U, class... A>
     void construct(U* p, A&&... a) {
         if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
         else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+    static size_t mapped_bytes(size_t n) { return (n * sizeof(T) + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE; }
+    T* allocate(size_t n) {
+        if (n * sizeof(T) < BIG) return std::allocator<T>::allocate(n);
+        void* p = mmap(nullptr, mapped_bytes(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(p, mapped_bytes(n), MADV_HUGEPAGE);            // (advice only: plain pages where huge pages are off)
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t n) {
+        if (n * sizeof(T) < BIG) std::allocator<T>::deallocate(p, n);
+        else (void)munmap(p, mapped_bytes(n));
     }
 };
 using ByteVec = std::vector<uint8_t, NoInitAlloc<uint8_t>>;
@@ -136,6 +152,7 @@ inline bool parse_plain(const char* base, size_t size, Records& out, std::string
     if (out.lens.size() > size_t(0x7FFFFFFF)) { err = "too many FASTA records"; return false; }
     std::vector<int64_t> start(out.lens.size() + 1, 0);
     for (size_t r = 0; r < out.lens.size(); ++r) start[r + 1] = start[r] + out.lens[r] + 1;
+    out.stage.reserve(size_t(start[out.lens.size()]) + 64);          // (room for the caller's padding to a multiple of 32: no reallocation later)
     out.stage.resize(size_t(start[out.lens.size()]));
     // leading bytes of chunk t continue the record that was open when the chunk began: behind what earlier chunks gave it
     {
@@ -199,6 +216,7 @@ inline bool parse_gz(const char* path, Records& out, std::string& err) {
     gzclose(fh);
     if (!carry.empty()) handle_line(carry.data(), carry.data() + carry.size());
     if (in_record) out.stage.push_back(0);
+    out.stage.reserve(out.stage.size() + 64);                        // (as parse_plain: room for the caller's padding)
     if (bad) { err = "FASTA header without a name"; return false; }
     if (out.lens.size() > size_t(0x7FFFFFFF)) { err = "too many FASTA records"; return false; }
     return true;

@@ -77,3 +77,22 @@ def test_parallel_path_chunk_boundaries(tmp_path):
         fh.write(b">last\n" + b"ACGT" * 800_000)                     # no trailing newline, 3.2 MB line
     assert os.path.getsize(path) > (1 << 24)
     _check(path)
+
+
+def test_large_record_buffer_paths(tmp_path):
+    """Sequence buffers of 64 MB and more come from mmap with huge pages asked for (plain files: one allocation; .gz: a buffer
+    that grows).  One 70 MB record + a short one: both readers must agree with each other and with the sizes written."""
+    rng = np.random.default_rng(11)
+    big = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=70_000_000).tobytes()
+    path = tmp_path / "large.fa"
+    with open(path, "wb") as fh:
+        fh.write(b">big one\n")
+        for o in range(0, len(big), 1_000_000):
+            fh.write(big[o:o + 1_000_000] + b"\n")
+        fh.write(b">small\nACGTACGT\n")
+    gz = tmp_path / "large.fa.gz"
+    with open(path, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
+        dst.write(src.read())
+    a, b = _native(path), _native(gz)
+    assert a[0] == 0 and a[1] == 2 and a[2] == 70_000_008
+    assert a == b
