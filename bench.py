@@ -317,6 +317,11 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
                          "kernel": "scan8_kernel: the two bulk launches of a scan (15/16 of the rows, and the last 1/16 on a second stream while the first rows go to the host) + its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them",
                          "algorithmic_bytes_per_launch": b_alg,
+                         "bulk_launches_per_scan": row_segments,
+                         "duration_ms": scan_avg,
+                         "duration_note": "achieved = algorithmic bytes of ONE SCAN / HIP-event time over all of its launches; "
+                                          "rocprofv3 --stats lists the bulk kernel with two launches per scan (about 7.6 ms + "
+                                          "0.6 ms, one after the other): its 'average' there is their mean, the scan is their sum",
                          "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
                                  "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding`"},
             "binding": binding,
