@@ -1223,8 +1223,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         }
         c->scan_stat[0] = bulk;
         // Rows [r0, r1) of this scan on stream `st`: bulk launch, the two hand-over launches, the rows' scalar tail, and the
-        // rows to the host.  Segment `seg` has its own slice of the two lists and its own counters (0: [0], [1]; 1: [4], [5]);
-        // the sample's hand-overs (list 1 from entry 0, counter [0]) belong to segment 0.
+        // rows' scalar tail.  Segment `seg` has its own slice of the two lists (from entry r0) and its own 32 counters: [0], [1]
+        // the lists' lengths, [8..15] the bulk launch's chunk queues (one per XCD), [16] the 8-bit launch's.
         auto run_rows = [&](int seg, int64_t r0, int64_t r1, hipStream_t st, bool fork_tail) -> int {
             const int64_t m = r1 - r0;
             ScanParams R = P;
