@@ -720,3 +720,21 @@ def test_orders_above_eight_against_c_oracle(kmin, kmax, w, inc, rip):
     assert len(kd) == len(exp_dbg["kld"]) >= 1
     assert np.array_equal(dbg.counts[kd].astype(np.int64), exp_dbg["counts"].astype(np.int64))
     assert np.array_equal(dbg.meta[kd], exp_dbg["meta"])
+
+
+@pytest.mark.parametrize("kmin,kmax,w,inc,rip,n", [(1, 8, 5000, 1000, True, 3_000_000), (1, 8, 3000, 20, False, 3_000_000),
+                                                    (2, 6, 2000, 500, True, 1_000_000), (1, 4, 5000, 1000, True, 400_000)])
+def test_page_locked_result_buffers_equal_ordinary_ones(kmin, kmax, w, inc, rip, n):
+    """Engine.scan(pinned=True) returns views of page-locked buffers (frisk_host_alloc: what bench.py times); the default is
+    ordinary numpy arrays.  Same bits either way - short and long (two row segments) scans, and the 16-bit form (k <= 4)."""
+    from frisk_amd import synth
+    seqs = [synth.scaffold(n, 5, 0, island_frac=0.05, n_frac=0.03, lower_frac=0.02), synth.scaffold(7000, 6, 0)]
+    with make_engine(kmin, kmax) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        a = e.scan(w, inc, rip=rip, scaffolds_all=True)
+        b = e.scan(w, inc, rip=rip, scaffolds_all=True, pinned=True)
+        cols = ("seq_index", "start", "stop", "status", "kld", "gc") + (("pi", "si", "cri") if rip else ())
+        for f in cols:
+            assert np.array_equal(getattr(a, f), np.array(getattr(b, f)), equal_nan=True), f
+        assert a.n_candidates == b.n_candidates and int(a.kept.sum()) > 0
