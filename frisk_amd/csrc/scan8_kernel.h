@@ -289,12 +289,14 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const int shc = 32 - int(gl & 15) * 2, shm = 32 - int(gl & 31);
             // (requesting the NEXT window's words after stage 4, to have them in registers here: measured +-0 at K = 8, -2 % at
             //  K = 6, 7 - with three or four workgroups per CU the other windows' waves already cover these two round trips)
+            // (all seven words requested before the first is used: one round trip to L2 / HBM, not two)
             const uint32_t w0 = P.codes[wi], w1 = P.codes[wi + 1], w2 = P.codes[wi + 2];
+            const uint32_t i0 = P.inv[mi], i1 = P.inv[mi + 1], l0 = P.low[mi], l1 = P.low[mi + 1];
             const uint32_t chi = uint32_t(((uint64_t(w0) << 32) | w1) >> shc);
             const uint32_t clo = uint32_t(((uint64_t(w1) << 32) | w2) >> shc);
             const uint64_t acode = (uint64_t(chi) << 32) | clo;             // bases j0 .. j0+31, first base in the top bits
-            const uint32_t ainv = uint32_t(((uint64_t(P.inv[mi]) << 32) | P.inv[mi + 1]) >> shm);
-            const uint32_t alow = uint32_t(((uint64_t(P.low[mi]) << 32) | P.low[mi + 1]) >> shm);
+            const uint32_t ainv = uint32_t(((uint64_t(i0) << 32) | i1) >> shm);
+            const uint32_t alow = uint32_t(((uint64_t(l0) << 32) | l1) >> shm);
             auto topbits = [](int k) -> uint32_t {
                 k = k < 0 ? 0 : (k > 32 ? 32 : k);
                 return uint32_t(0xFFFFFFFF00000000ull >> k);
