@@ -504,10 +504,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // has bit 15 set and holds its (K-2)-mer << 2.  o6[k] = the (K-2)-mer of entry k (both kinds count towards c6), o7[k] =
             // the (K-1)-mer of a run-(K-1) entry.  A window without invalid bases has exactly one of each kind (its tail).
             uint32_t o6[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, o7[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            const uint2 first4 = *reinterpret_cast<const uint2*>(orph);            // (one read for the four, not four round trips)
+            static_assert(L::orphans % 8 == 0, "the orphan list is read eight bytes at a time");
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k < n_orph) {
-                    const uint32_t e = uni(uint32_t(orph[k]));
+                    const uint32_t e = uni(((k < 2 ? first4.x : first4.y) >> (16 * (k & 1))) & 0xFFFFu);
                     o6[k] = (e >> 2) & (NK / 16u - 1u);
                     if (!(e & 0x8000u)) o7[k] = e;
                 }
@@ -614,26 +616,31 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         if constexpr (FUSED) {
                             const uint64_t d64 = (uint64_t(ch.y) << 32) | ch.x;
                             const unsigned char* mine = t8b + q4 * (BITS == 8 ? 256u : 128u);
+                            // (all of the thread's table bytes requested before the first is summed: one LDS round trip, not eight)
+                            constexpr int NH = BITS == 8 ? 4 : 2;
+                            uint4 x[4][NH];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                const uint32_t j = (uint32_t(m) + uint32_t(tid)) & 3u;
+#pragma unroll
+                                for (int h = 0; h < NH; ++h) {
+                                    const uint32_t hh = BITS == 8 ? ((uint32_t(h) + (uint32_t(tid) >> 1)) & 3u) : ((uint32_t(h) + (uint32_t(tid) >> 2)) & 1u);
+                                    x[m][h] = *reinterpret_cast<const uint4*>(mine + j * (BITS == 8 ? 64u : 32u) + hh * 16u);
+                                }
+                            }
                             uint32_t tot = 0;
 #pragma unroll
                             for (int m = 0; m < 4; ++m) {
                                 const uint32_t j = (uint32_t(m) + uint32_t(tid)) & 3u;
                                 uint32_t sm = 0;
-                                if (BITS == 8) {
 #pragma unroll
-                                    for (int h = 0; h < 4; ++h) {
-                                        const uint32_t hh = (uint32_t(h) + (uint32_t(tid) >> 1)) & 3u;
-                                        const uint4 x = *reinterpret_cast<const uint4*>(mine + j * 64u + hh * 16u);
-                                        sm = __builtin_amdgcn_sad_u8(x.x, 0u, sm); sm = __builtin_amdgcn_sad_u8(x.y, 0u, sm);
-                                        sm = __builtin_amdgcn_sad_u8(x.z, 0u, sm); sm = __builtin_amdgcn_sad_u8(x.w, 0u, sm);
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int h = 0; h < 2; ++h) {
-                                        const uint32_t hh = (uint32_t(h) + (uint32_t(tid) >> 2)) & 1u;
-                                        const uint4 x = *reinterpret_cast<const uint4*>(mine + j * 32u + hh * 16u);
-                                        sm = __builtin_amdgcn_udot8(x.x, 0x11111111u, sm, false); sm = __builtin_amdgcn_udot8(x.y, 0x11111111u, sm, false);
-                                        sm = __builtin_amdgcn_udot8(x.z, 0x11111111u, sm, false); sm = __builtin_amdgcn_udot8(x.w, 0x11111111u, sm, false);
+                                for (int h = 0; h < NH; ++h) {
+                                    if (BITS == 8) {
+                                        sm = __builtin_amdgcn_sad_u8(x[m][h].x, 0u, sm); sm = __builtin_amdgcn_sad_u8(x[m][h].y, 0u, sm);
+                                        sm = __builtin_amdgcn_sad_u8(x[m][h].z, 0u, sm); sm = __builtin_amdgcn_sad_u8(x[m][h].w, 0u, sm);
+                                    } else {
+                                        sm = __builtin_amdgcn_udot8(x[m][h].x, 0x11111111u, sm, false); sm = __builtin_amdgcn_udot8(x[m][h].y, 0x11111111u, sm, false);
+                                        sm = __builtin_amdgcn_udot8(x[m][h].z, 0x11111111u, sm, false); sm = __builtin_amdgcn_udot8(x[m][h].w, 0x11111111u, sm, false);
                                     }
                                 }
                                 tot += sm;
@@ -652,18 +659,22 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     uint32_t below4 = 0;                // K = 7, fused form: the 64 order-7 counters (bytes) below the 4-mer
                     if constexpr (LV == 4 && FUSED) {
                         const unsigned char* mine = t8b + q4 * 64u;
+                        uint4 x[4];
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) x[h] = *reinterpret_cast<const uint4*>(mine + ((uint32_t(h) + (uint32_t(tid) >> 1)) & 3u) * 16u);
 #pragma unroll
                         for (int h = 0; h < 4; ++h) {
-                            const uint32_t hh = (uint32_t(h) + (uint32_t(tid) >> 1)) & 3u;
-                            const uint4 x = *reinterpret_cast<const uint4*>(mine + hh * 16u);
-                            below4 = __builtin_amdgcn_sad_u8(x.x, 0u, below4); below4 = __builtin_amdgcn_sad_u8(x.y, 0u, below4);
-                            below4 = __builtin_amdgcn_sad_u8(x.z, 0u, below4); below4 = __builtin_amdgcn_sad_u8(x.w, 0u, below4);
+                            below4 = __builtin_amdgcn_sad_u8(x[h].x, 0u, below4); below4 = __builtin_amdgcn_sad_u8(x[h].y, 0u, below4);
+                            below4 = __builtin_amdgcn_sad_u8(x[h].z, 0u, below4); below4 = __builtin_amdgcn_sad_u8(x[h].w, 0u, below4);
                         }
                         const uint32_t tot = wave_sum_u32(below4);
                         if (lane == 0 && tot) atomicAdd(&misc[M8_TSUM], tot);
                     }
+                    // (the D counts of all four lower orders requested up front, before the DPP sums that they are added to - an order
+                    //  that is off reads a harmless bin of the first table)
+                    const uint32_t d4 = small16[ox[4] + q4], d3 = small16[ox[3] + (q4 >> 2)], d2 = small16[ox[2] + (q4 >> 4)], d1 = small16[q4 >> 6];
                     if (kmin <= 4) {
-                        cx[4] = small16[ox[4] + q4] + below4;
+                        cx[4] = d4 + below4;
                         if constexpr (LV == 4 && FUSED) small16[ox[4] + q4] = uint16_t(cx[4]);
                         if constexpr (LV == 5) {
                             cx[4] += c5[0] + c5[1] + c5[2] + c5[3];
@@ -672,17 +683,17 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         if (kmin <= 3) {
                             uint32_t qs = dpp_addu<0xB1>(cx[4]);
                             qs = dpp_addu<0x4E>(qs);                                             // the quad's sum, in all four lanes
-                            cx[3] = small16[ox[3] + (q4 >> 2)] + qs;                             // (every lane of the quad reads, then one writes)
+                            cx[3] = d3 + qs;                                                     // (every lane of the quad has read D_3; one writes C_3)
                             if ((lane & 3) == 0) small16[ox[3] + (q4 >> 2)] = uint16_t(cx[3]);
                             if (kmin <= 2) {
                                 uint32_t rs = dpp_addu<0xB1>((lane & 3) == 0 ? cx[3] : 0u);
                                 rs = dpp_addu<0x4E>(rs); rs = dpp_addu<0x141>(rs); rs = dpp_addu<0x140>(rs);   // the row's four C_3, in all 16 lanes
-                                cx[2] = small16[ox[2] + (q4 >> 4)] + rs;
+                                cx[2] = d2 + rs;
                                 if ((lane & 15) == 0) small16[ox[2] + (q4 >> 4)] = uint16_t(cx[2]);
                                 if (kmin <= 1) {
                                     const uint32_t ws = __builtin_amdgcn_readlane(int(cx[2]), 0) + __builtin_amdgcn_readlane(int(cx[2]), 16) +
                                                         __builtin_amdgcn_readlane(int(cx[2]), 32) + __builtin_amdgcn_readlane(int(cx[2]), 48);
-                                    cx[1] = small16[q4 >> 6] + ws;
+                                    cx[1] = d1 + ws;
                                     if (lane == 0) small16[q4 >> 6] = uint16_t(cx[1]);
                                 }
                             }
