@@ -40,6 +40,9 @@
 #ifndef FRISK8_SHORT_LANES
 #define FRISK8_SHORT_LANES 6        // stage 1: up to this many lanes of a wave with short words get a pass each (more: per position)
 #endif
+#ifndef FRISK8_PRIO
+#define FRISK8_PRIO 3               // wave priority (s_setprio) of every stage but the scoring loop; 0 = no priorities
+#endif
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
 enum { M8_TSUM = 6,                // misc slots: grand total of the order-8 table (overflow check) ...
@@ -145,6 +148,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     auto clear_small = [&]() {
         for (uint32_t i = tid0; i < L::small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
     };
+#if FRISK8_PRIO
+    __builtin_amdgcn_s_setprio(FRISK8_PRIO);
+#endif
     clear_t8();
     clear_small();
     if (tid0 < 2 * FRISK8_SLOTS) misc_base[tid0] = 0;
@@ -788,6 +794,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             //      Sw = sum Iw/c8,  Sg = sum Ig/c8,  T = sum Iw ln(Iw/Ig)/c8  over POSITIONS (= sums over distinct max-mers)
             const double r6 = r_of(K - 2), r7 = r_of(K - 1), r8 = r_of(K);      // (named for K = 8: the three orders above the prefix)
             double sw = 0.0, sg = 0.0, stt = 0.0;
+#if FRISK8_PRIO
+            // The long scoring loop yields issue slots to the short stages of the other workgroups' windows: those are chains of
+            // dependent steps between barriers, where a lost slot delays four waves, while a scoring wave has work for every slot
+            // it gets.  Measured +3..4 % (all short stages high, scoring low; raising only some of them: less).
+            __builtin_amdgcn_s_setprio(0);
+#endif
             // (a << SH) + b in one instruction (the compiler's own choice for the weight below is two shifts, a shift-add and an add3)
             auto shl_add = [](uint32_t a, auto sh, uint32_t b) __attribute__((always_inline)) -> uint32_t {
                 uint32_t r;
@@ -938,6 +950,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             else score_all(std::false_type{}, orphN{});
 
             // workgroup totals in a fixed order: DPP butterfly per wave, then the NW partials in wave order
+#if FRISK8_PRIO
+            __builtin_amdgcn_s_setprio(FRISK8_PRIO);
+#endif
             STAMP(6)
             sw = wave_sum_exact(sw); sg = wave_sum_exact(sg); stt = wave_sum_exact(stt);
             if (lane == 0) { double* p = scratch + (tid >> 6) * 3; p[0] = sw; p[1] = sg; p[2] = stt; }
