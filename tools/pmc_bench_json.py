@@ -73,7 +73,7 @@ out = {
         "fp64_lane_ops_peak_per_s": 78.6e12 / 2.0,       # 78.6 TFLOP/s vector FP64 = 39.3 T fused multiply-add lanes per second
         "fp64_frac_of_vector_peak": fp64_lane_ops / (78.6e12 / 2.0),
         "note": "between VALU issue and latency: the SIMDs' VALU is busy most of the time, the waves of a window are short dependent "
-                "stages between five barriers, three workgroups per CU; LDS and HBM are far from their limits",
+                "stages between four barriers, three workgroups per CU; LDS and HBM are far from their limits",
     },
 }
 json.dump(out, sys.stdout, indent=1)
