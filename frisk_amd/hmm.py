@@ -108,17 +108,32 @@ class GaussianHMM2:
         return path
 
 
-def state_runs(states, value):
-    """(first, last) index of every maximal run of `value` (findBaseRanges L91-104 with minlen 0: single
-    windows are runs too)."""
+def findBaseRanges(s, ch, name=None, minlen=0):
+    """(first, last) index - or (name, first, last) - of every maximal run of `ch` in `s` whose span last - first is not
+    below minlen (L91-104: the test is `<`, so minlen 0 keeps single elements)."""
     runs, start = [], None
-    for i, s in enumerate(list(states) + [None]):
-        if s == value and start is None:
+    n = len(s)
+    for i in range(n + 1):
+        hit = i < n and s[i] == ch
+        if hit and start is None:
             start = i
-        elif s != value and start is not None:
-            runs.append((start, i - 1))
+        elif not hit and start is not None:
+            if (i - 1) - start >= minlen:
+                runs.append((name, start, i - 1) if name else (start, i - 1))
             start = None
     return runs
+
+
+def state_runs(states, value):
+    """Runs of one HMM state, single windows included (how hmm2BED L778-779 calls findBaseRanges)."""
+    return findBaseRanges(states, value)
+
+
+def range2interval(rangeList, windows, state):
+    """Runs of window indices -> (name, start of the first window, stop of the last, state), all strings (L787-795).
+    windows: the scaffold's scored rows (name, start, stop, ...) in table order."""
+    for first, last in rangeList:
+        yield (str(windows[0][0]), str(int(windows[first][1])), str(int(windows[last][2])), str(state))
 
 
 def hmm2BED(rows, model=None):
@@ -159,8 +174,7 @@ def hmm2BED(rows, model=None):
         win = [r for r in good if r[0] == name]
         states = model.predict(np.array([float(r[3]) for r in win]))
         for value, label in ((0, "State1"), (1, "State2")):
-            for a, b in state_runs(states.tolist(), value):
-                out.append((str(name), str(int(win[a][1])), str(int(win[b][2])), label))
+            out.extend(range2interval(state_runs(states.tolist(), value), win, label))
     return sorted(out, key=lambda t: (t[0], t[1], t[2])), model
 
 

@@ -10,6 +10,8 @@ with the three metadata dicts appended (L356-359), and rows (name, start, stop, 
 SI, CRI]) in the reference's order.  Where the reference would die with ZeroDivisionError
 (L437: a window max-mer whose prefix has zero weight in the genome) scanGenome raises it too.
 """
+import logging
+
 import numpy as np
 
 from . import _ffi
@@ -47,6 +49,47 @@ def mapsToProfile(maps, kMin, kMax):
         flat.extend(d[kmerString(c, x)] for c in range(4 ** x))
     r = kMax - kMin
     return (np.asarray(flat, dtype=np.int64), maps[r + 1]["totalLen"], maps[r + 2]["exMax"], maps[r + 3]["nnTotal"])
+
+
+def crawlLog(names, sizes, seq_index, kept, w, inc, scaffolds_all, emit=None):
+    """The progress lines crawlGenome logs per scaffold (L212-250), from the scan's per-candidate arrays: small scaffolds
+    skipped / rescued / dropped, `Extracted N windows from S bases in NAME`, `Excluded N windows from NAME`, and the closing
+    `Successfully processed sequences` count (a rescued scaffold counts twice there, as in the reference: L221 and L250).
+    The reference also logs one line per window that the N filter drops (L238); those go to the DEBUG level here -
+    a 3 Gb assembly has 2e5 of them."""
+    log = logging.getLogger("frisk_amd")
+    emit = emit or log.info
+    n = len(names)
+    seq_index = np.asarray(seq_index, dtype=np.int64)
+    cand = np.bincount(seq_index, minlength=n) if seq_index.size else np.zeros(n, np.int64)
+    good = np.bincount(seq_index[np.asarray(kept, dtype=bool)], minlength=n) if seq_index.size else np.zeros(n, np.int64)
+    limit = w + ((w * 0.75) - inc)
+    done = 0
+    for s in range(n):
+        name, size = names[s], int(sizes[s])
+        count, dropped = int(good[s]), int(cand[s] - good[s])
+        if size <= limit and scaffolds_all:
+            if dropped:
+                emit("%s excluded as > 30 percent unresolved sequence." % name)
+                continue
+            emit("Rescuing small scaffold %s" % name)
+            done += 1
+        elif size <= limit:
+            emit("%s excluded as below minimum scaffold length of %s." % (name, _py2_float(limit)))
+            continue
+        elif dropped and log.isEnabledFor(logging.DEBUG):
+            for _ in range(dropped):
+                log.debug("Window from %s excluded as > 30 percent unresolved sequence." % name)
+        emit("Extracted %s windows from %s bases in %s" % (count, str(size), name))
+        emit("Excluded %s windows from %s" % (dropped, name))
+        done += 1
+    emit("Successfully processed sequences: %s" % done)
+    return done
+
+
+def _py2_float(x):
+    s = "%.12g" % x
+    return s if ("." in s or "e" in s) else s + ".0"
 
 
 class HotPath:
@@ -102,6 +145,8 @@ class HotPath:
         # (ordinary numpy arrays: `res` is handed to the caller and must outlive the next scan and Engine.close())
         res = self.engine.scan(args.windowlen, args.increment, rip=rip,
                                scaffolds_all=bool(getattr(args, "scaffoldsAll", False)), debug=debug, pinned=False)
+        crawlLog(self.names, self.engine.seq_lens, res.seq_index, res.kept, args.windowlen, args.increment,
+                 bool(getattr(args, "scaffoldsAll", False)))
         kept = np.nonzero(res.kept)[0]
         bad = kept[(res.status[kept] & _ffi.ROW_ZERO_WEIGHT) != 0]
         tolerate = bool(getattr(args, "tolerateZeroWeight", False))

@@ -8,14 +8,19 @@ from golden_util import GOLD, INPUTS, Case
 
 pytestmark = pytest.mark.gpu
 
+WRITERS = json.load(open(os.path.join(GOLD, "writers.json")))
+
 
 def test_cli_table_caches_and_gff(tmp_path, capsys, monkeypatch):
     from frisk_amd import postprocess as pp
     from frisk_amd.cli import main
     c = Case("markov_k6")
     out = tmp_path / "T"
-    argv = ["-H", c.host, "-k", "6", "-w", "400", "-i", "150", "--RIP", "-t", str(out), "-F", "0.08", "--gffOutfile", "anom.gff3",
-            "--mergeDist", "10"]
+    g = WRITERS["e2e"]["markov_k6"]      # what the reference's own thresholdKLD / anomaly2GFF / thresholdRIP / RIP2GFF write
+    argv = ["-H", c.host, "-k", "6", "-w", "400", "-i", "150", "--RIP", "-t", str(out), "-F", str(g["forceThresholdKLD"]),
+            "--gffOutfile", "anom.gff3", "--mergeDist", str(g["mergeDist"])]
+    for opt, val in g["rip_args"].items():
+        argv += ["--" + opt + "=" + str(val)]
     assert main(argv) == 0
     printed = capsys.readouterr().out.splitlines()
     table = open(out / "raw_window_scores.bed").read().splitlines()
@@ -34,10 +39,9 @@ def test_cli_table_caches_and_gff(tmp_path, capsys, monkeypatch):
         assert f[5:] == [pp.py2_str(v) for v in exp["RIP"]]
     assert same_text >= 0.9 * len(c.rows)
     assert os.path.isfile(out / c.doc["genome_pickle_basename"]) and os.path.isfile(out / c.doc["window_pickle_basename"])
-    gff = open(out / "anom.gff3").read().splitlines()
-    assert gff[0] == "##gff-version 3" and all(g.split("\t")[1] == "frisk_0+unknown" for g in gff[1:])
-    n_hot = sum(1 for r in c.rows if r["KLD"] >= 0.08)
-    assert 1 <= len(gff) - 1 <= n_hot
+    # both feature files byte for byte: the reference's post-processing on the reference's scores for these windows
+    assert open(out / "anom.gff3").read() == g["anomaly_gff"] and g["anomaly_gff"].count("\n") > 3
+    assert open(out / "RIP_annotation.gff3").read() == g["rip_gff"] and g["rip_gff"].count("\n") > 1
     # second run: both caches are reused (no recomputation), same table; py3 float text on request
     monkeypatch.setenv("FRISK_FLOAT_REPR", "py3")
     os.remove(out / "raw_window_scores.bed")
@@ -78,34 +82,31 @@ def test_cli_sharded_path_in_one_rank_group(tmp_path, capsys, monkeypatch):
     assert len(plain.splitlines()) == 1 + len(c.rows)
 
 
-def test_cli_hmm_segmentation_gff(tmp_path):
-    """--hmmKLD --hmmOutfile end to end on the GPU (reference L1537-1548, hmm2BED L757-785, hmmBED2GFF L589-596): the
-    GFF3 text the CLI writes equals the text that the host-side model produces from the score table the same run wrote
-    (the model's numbers are parity-unpinned - hmmlearn is absent - but stacking, per-scaffold decoding, run extraction,
-    ordering and the GFF3 layout are the reference's)."""
-    from frisk_amd import postprocess as pp
+@pytest.mark.parametrize("case", ["markov_m2k4", "k8_w2000", "markov_k6"])
+def test_cli_hmm_segmentation_gff(tmp_path, case):
+    """--hmmKLD --hmmOutfile end to end on the GPU (reference L1537-1548): the GFF3 files equal, byte for byte, what the
+    REFERENCE'S hmm2BED L757-785 / findBaseRanges / range2interval / hmmBED2GFF L589-596 and thresholdKLD / anomaly2GFF
+    write for the reference's scores of these windows (tests/golden/writers.json).  Only the model's numbers are this
+    package's own (hmmlearn is absent: the golden was made by handing this package's model to the reference's hmm2BED);
+    the GPU's scores, within 1e-11 of the reference's, move no window across a state or threshold boundary."""
     from frisk_amd.cli import main
-    from frisk_amd.hmm import hmm2BED, hmmBED2GFF
-    c = Case("markov_k6")
+    c = Case(case)
+    g = WRITERS["e2e"][case]
+    a = c.doc["args"]
     out = tmp_path / "H"
-    assert main(["-H", c.host, "-k", "6", "-w", "400", "-i", "150", "-t", str(out), "-F", "0.08", "--hmmKLD",
-                 "--hmmOutfile", "states.gff3", "--gffOutfile", "anom.gff3"]) == 0
-    table = [ln.split("\t") for ln in open(out / "raw_window_scores.bed").read().splitlines()[1:]]
-    assert len(table) == len(c.rows)
-    rows = [(f[0], int(f[1]), int(f[2]), exp["KLD"], exp["GC"]) for f, exp in zip(table, c.rows)]
-    gff = open(out / "states.gff3").read()
-    lines = gff.splitlines()
-    assert lines[0] == "##gff-version 3"
-    feats = [ln.split("\t") for ln in lines[1:]]
-    assert len(feats) >= 2 and all(len(f) == 9 for f in feats)
-    assert all(f[1] == "frisk_" + pp.FRISK_VERSION for f in feats)
-    assert {f[0] for f in feats} <= {r[0] for r in rows}
-    assert all(1 <= int(f[3]) <= int(f[4]) for f in feats)
-    # the same model on the reference's golden KLD values for these windows gives the same features: the GPU's scores
-    # (within 1e-11 of the reference's) do not move any window across a state boundary
-    intervals, _ = hmm2BED(rows)
-    assert "".join(hmmBED2GFF(intervals)) == gff
-    assert open(out / "anom.gff3").read().startswith("##gff-version 3")
+    argv = ["-H", c.host, "-m", str(a["minWordSize"]), "-k", str(a["maxWordSize"]), "-w", str(a["windowlen"]),
+            "-i", str(a["increment"]), "-t", str(out), "-F", str(g["forceThresholdKLD"]), "--mergeDist", str(g["mergeDist"]),
+            "--hmmKLD", "--hmmOutfile", "states.gff3", "--gffOutfile", "anom.gff3"]
+    if g["rip_args"] is not None:
+        argv += ["--RIP"] + ["--" + opt + "=" + str(val) for opt, val in g["rip_args"].items()]
+    assert main(argv) == 0
+    assert len(open(out / "raw_window_scores.bed").read().splitlines()) == 1 + len(c.rows)
+    assert open(out / "states.gff3").read() == g["hmm_gff"]
+    assert open(out / "anom.gff3").read() == g["anomaly_gff"]
+    if g["rip_args"] is not None:
+        assert open(out / "RIP_annotation.gff3").read() == g["rip_gff"]
+    if case != "markov_k6":
+        assert "State1" in g["hmm_gff"] and "State2" in g["hmm_gff"]
 
 
 def test_cli_sharded_cache_semantics(tmp_path, monkeypatch):
@@ -159,3 +160,21 @@ def test_cli_zero_weight_writes_the_rows_before_the_failure(tmp_path, capsys):
     assert len(table) == 1 + first_bad
     assert capsys.readouterr().out.splitlines()[1:] == table[1:]
     assert not any(f.endswith("KLD_window_500_increment_100.p") for f in os.listdir(tmp_path / "Z"))
+
+
+@pytest.mark.parametrize("case", ["smalls_all", "smalls_skip", "nheavy_k4", "overshoot"])
+def test_cli_logs_the_reference_progress_lines(tmp_path, caplog, case):
+    """crawlGenome's per-scaffold lines (L212-250) from the GPU scan's own candidate arrays equal the reference's."""
+    import logging
+    from frisk_amd.cli import main
+    c = Case(case)
+    a = c.doc["args"]
+    argv = ["-H", c.host, "-m", str(a["minWordSize"]), "-k", str(a["maxWordSize"]), "-w", str(a["windowlen"]),
+            "-i", str(a["increment"]), "-t", str(tmp_path / "L"), "--exitAfter", "WindowKLD"]
+    argv += ["--scaffoldsAll"] if a["scaffoldsAll"] else []
+    with caplog.at_level(logging.INFO, logger="frisk_amd"):
+        assert main(argv) == 0
+    want = [ln for ln in WRITERS["crawl_log"][case] if not ln.startswith("Window from ")]
+    got = [r.getMessage() for r in caplog.records if r.name == "frisk_amd"]
+    first = got.index(want[0])
+    assert got[first:first + len(want)] == want
