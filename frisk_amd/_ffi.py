@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRISK_HIP_LIB") or os.path.join(_HERE, "libfrisk_hip.so")   # override: kernel experiments
 
 OK, E_ARG, E_HIP, E_STATE, E_CAP, E_ZERO_WEIGHT = 0, -1, -2, -3, -4, -5
-SCAN_RIP, SCAN_SCAFFOLDS_ALL = 1, 2
+SCAN_RIP, SCAN_SCAFFOLDS_ALL, SCAN_CHUNKS = 1, 2, 256
 ROW_KEPT, ROW_ZERO_WEIGHT, ROW_JUMPBACK, ROW_NO_MAXMER = 1, 2, 4, 8
 
 # every symbol include/frisk_hip.h declares: (name, restype, argtypes)
@@ -36,7 +36,7 @@ SYMBOLS = [
     ("frisk_seq_count", C.c_int32, [_P]),
     ("frisk_seq_name", C.c_char_p, [_P, C.c_int32]),
     ("frisk_seq_len", C.c_int64, [_P, C.c_int32]),
-    ("frisk_seq_synth", C.c_int, [_P, _I64P, C.c_int32, C.c_uint64, C.c_double, C.c_double, C.c_double]),
+    ("frisk_seq_synth", C.c_int, [_P, _I64P, C.c_int32, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double]),
     ("frisk_seq_read", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("frisk_profile_reset", C.c_int, [_P]),
     ("frisk_profile_add", C.c_int, [_P, C.c_int, C.c_int64, C.c_int64]),

@@ -106,6 +106,8 @@ struct frisk_ctx {
     hipStream_t tail_stream = nullptr;      // frisk_scan: the last sixteenth of a long scan, while the rows of the rest go to the host
     hipEvent_t ev_fork = nullptr, ev_tail_kernels = nullptr, ev_tail_done = nullptr;
     hipEvent_t staged_ev = nullptr;         // recorded behind the staged batch's last operation
+    hipEvent_t slot_free_ev = nullptr;      // recorded on `stream` at every commit: everything queued there before it may still read the
+    bool slot_ev_set = false;               // batch slot that the NEXT stage overwrites (profile kernels and scans are asynchronous)
     bool staged = false;
 
     // profile
@@ -452,6 +454,7 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
     HIPC(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPC(c, hipEventCreateWithFlags(&c->staged_ev, hipEventDisableTiming));
+    HIPC(c, hipEventCreateWithFlags(&c->slot_free_ev, hipEventDisableTiming));
     HIPC(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
     HIPC(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPC(c, hipEventCreateWithFlags(&c->ev_tail_kernels, hipEventDisableTiming));
@@ -504,6 +507,7 @@ void frisk_destroy(frisk_ctx* c) {
     c->o_ivom.release(); c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->staged_ev) (void)hipEventDestroy(c->staged_ev);
+    if (c->slot_free_ev) (void)hipEventDestroy(c->slot_free_ev);
     for (int i = 0; i < frisk_ctx::PIN_N; ++i) {
         if (c->pin_ev[i]) { (void)hipEventSynchronize(c->pin_ev[i]); (void)hipEventDestroy(c->pin_ev[i]); }
         if (c->pin_buf[i]) (void)hipHostFree(c->pin_buf[i]);
@@ -719,6 +723,8 @@ int frisk_seq_stage(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* len
     HIPC(c, hipSetDevice(c->device));
     frisk_ctx::Batch& B = c->bat[c->cur ^ 1];
     c->staged = false;
+    // work queued on the compute stream before the last commit may still be reading this slot
+    if (c->slot_ev_set) HIPC(c, hipStreamWaitEvent(c->copy_stream, c->slot_free_ev, 0));
     int rc = layout_batch(c, B, lens, n_seq);
     if (rc) return rc;
     rc = enqueue_ascii_upload(c, B, seqs, lens, n_seq, c->copy_stream);
@@ -739,6 +745,7 @@ int frisk_seq_stage_packed(frisk_ctx* c, const uint32_t* codes, const uint32_t* 
     HIPC(c, hipSetDevice(c->device));
     frisk_ctx::Batch& B = c->bat[c->cur ^ 1];
     c->staged = false;
+    if (c->slot_ev_set) HIPC(c, hipStreamWaitEvent(c->copy_stream, c->slot_free_ev, 0));      // (as frisk_seq_stage)
     int rc = layout_batch(c, B, lens, n_seq);
     if (rc) return rc;
     rc = alloc_packed(c, B, c->copy_stream);
@@ -756,6 +763,9 @@ int frisk_seq_commit(frisk_ctx* c) {
     if (!c) return FRISK_E_ARG;
     if (!c->staged) return fail(c, FRISK_E_STATE, "frisk_seq_commit: no staged batch");
     HIPC(c, hipSetDevice(c->device));
+    // the slot that stops being resident here is the one the next stage fills: that upload waits for what is queued so far
+    HIPC(c, hipEventRecord(c->slot_free_ev, c->stream));
+    c->slot_ev_set = true;
     HIPC(c, hipStreamWaitEvent(c->stream, c->staged_ev, 0));   // the compute stream waits on the device; the host does not
     c->cur ^= 1;
     c->b().have_seq = true;
@@ -784,7 +794,7 @@ int frisk_seq_set_names(frisk_ctx* c, const char* const* names, int32_t n_seq) {
 }
 
 int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t seed, double island_frac,
-                    double n_frac, double lower_frac) {
+                    double n_frac, double lower_frac, double repeats_per_kb) {
     if (!c) return FRISK_E_ARG;
     if (n_seq > 0 && !lens) return fail(c, FRISK_E_ARG, "null length table");
     HIPC(c, hipSetDevice(c->device));
@@ -795,13 +805,14 @@ int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t s
     SynthTables tabs;
     synth_make_tables(seed, tabs);
     const uint32_t thr_island = synth_frac_to_u32(island_frac), thr_nbig = synth_frac_to_u32(n_frac * 0.8),
-                   thr_nsmall = synth_frac_to_u32(n_frac * 0.2), thr_low = synth_frac_to_u32(lower_frac);
+                   thr_nsmall = synth_frac_to_u32(n_frac * 0.2), thr_low = synth_frac_to_u32(lower_frac),
+                   thr_rep = synth_frac_to_u32(repeats_per_kb * (SYNTH_REP / 1000.0));
     for (int32_t s = 0; s < n_seq; ++s) {
         if (lens[s] <= 0) continue;
         const int64_t nblk = (lens[s] + SYNTH_BLOCK - 1) / SYNTH_BLOCK;
         synth_kernel<<<grid_for(nblk, 64, 1 << 20), 64, 0, c->stream>>>(c->b().d_ascii.p + c->b().seq_off[size_t(s)], lens[s],
                                                                        seed, uint32_t(s), tabs, thr_island, thr_nbig,
-                                                                       thr_nsmall, thr_low);
+                                                                       thr_nsmall, thr_low, thr_rep);
         HIPC(c, hipGetLastError());
     }
     rc = alloc_packed(c);
@@ -1076,7 +1087,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
     P.stamps = nullptr;
     P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
-    P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr; P.queue_n = 1;
+    P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr; P.queue_n = 1; P.slide_pp = 0;
     c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0; c->scan_stat[3] = 1;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
@@ -1114,7 +1125,8 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     const bool narrow8 = k8 && c->kmin <= 5 && w <= 5120 && c->plan_maxwin <= 65535 && (width == 0 || width == 4 || width == 8);
     // K = 6, 7: the same kernel with 8-bit counters (a K-mer must occur 256 times in a window to wrap one)
     const bool narrow7 = (c->kmax == 6 || c->kmax == 7) && c->kmin <= c->kmax - 3 && w <= 5120 && c->plan_maxwin <= 65535 && width != 16;
-    const bool narrow = narrow8 || narrow7;
+    // (the per-max-mer IVOM dump of frisk_scan_ivom is written by scan_kernel.h's debug instantiation only)
+    const bool narrow = (narrow8 || narrow7) && !c->want_ivom;
     // the 16-bit form (scan_kernel.h) over the candidates that PP names, by window class
     auto launch16 = [&](const ScanParams& PP, int g, hipStream_t st) -> hipError_t {
         hipError_t le;
@@ -1181,7 +1193,12 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 64 * sizeof(unsigned int), c->stream));
         const bool small_w = w <= 2048;
         int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), 8));
+        if (flags & FRISK_SCAN_CHUNKS) chunk8 = 8;
         if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk8 = std::max<int64_t>(1, std::atoll(ev));
+        // inside a chunk the order-K table slides from window to window where two windows share more than half their bases
+        // (2 inc updates instead of w - K + 1 and a cleared table; scan8_kernel.h)
+        if (2 * int64_t(inc) <= int64_t(w) - (c->kmax - 1) && chunk8 >= 2 && !tune_env("FRISK_NO_SLIDE"))
+            P.slide_pp = int32_t((inc + 255) / 256);
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
         // chunks dealt by counters (scan8_kernel.h) where a chunk is long enough to pay for the exchange: a short scan keeps the static deal
         const bool dealt = chunk8 >= 4;

@@ -43,6 +43,12 @@
 #ifndef FRISK8_PRIO
 #define FRISK8_PRIO 3               // wave priority (s_setprio) of every stage but the scoring loop; 0 = no priorities
 #endif
+#ifndef FRISK8_W7_READ
+#define FRISK8_W7_READ 0            // 4-bit form: 1 = the (K-1)-mer's four nibbles come from an LDS read of their own (round 2's form)
+#endif
+#ifndef FRISK8_PRE_SPLIT
+#define FRISK8_PRE_SPLIT 1          // shared prefix sums as two arrays - A[] read by one ds_read_b64, W[] by one ds_read_b32 - instead of
+#endif                              // interleaved 12-byte entries (a ds_read2_b32 and a ds_read_b32: half again as many LDS passes)
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
 enum { M8_TSUM = 6,                // misc slots: grand total of the order-8 table (overflow check) ...
@@ -77,7 +83,11 @@ __device__ inline double log_tab_n(double x, const double2* tab) {
     const double m = __builtin_amdgcn_frexp_mant(x);
     // (the bin's BYTE offset straight from the mantissa's top bits: shift + mask, no index scaling)
     const uint32_t off = (uint32_t(__double2hiint(m)) >> ((N == 128 ? 13 : (N == 64 ? 14 : 15)) - 4)) & (uint32_t(N - 1) << 4);
+#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 1)       // (experiment builds, wrong results: no table read)
+    const double2 e = make_double2(1.0 + double(off) * 0x1p-11, double(off) * -0x1p-11);
+#else
     const double2 e = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
+#endif
     const double r = __builtin_fma(m, e.x, -1.0);
     double p = (DEG & 1) ? 1.0 / DEG : -1.0 / DEG;
 #pragma unroll
@@ -135,6 +145,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     uint16_t* small16 = reinterpret_cast<uint16_t*>(lds + L::small);
     uint16_t* orph = reinterpret_cast<uint16_t*>(lds + L::orphans);
     Pre8* pre = reinterpret_cast<Pre8*>(lds + L::pre);
+    double* preA = reinterpret_cast<double*>(lds + L::pre);                    // (FRISK8_PRE_SPLIT: NL doubles, then NL words)
+    uint32_t* preW = reinterpret_cast<uint32_t*>(lds + L::pre + NL * 8);
+    auto put_pre = [&](uint32_t idx, double A, uint32_t W) __attribute__((always_inline)) {
+        if (FRISK8_PRE_SPLIT) { preA[idx] = A; preW[idx] = W; } else { pre[idx].A = A; pre[idx].W = W; }
+    };
     uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L::misc);
     double* scratch = reinterpret_cast<double*>(lds + L::misc + 2 * FRISK8_SLOTS * 4);
     const double2* logtab = reinterpret_cast<const double2*>(lds + L::logtab);
@@ -180,6 +195,17 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     d.cand0 = 0; d.ncand = 0; d.off = 0; d.size = 0; d.kind = 0; d.base0 = 0; d.j0 = 0;
     int dsi = -1;
     uint32_t parity = 0;
+    // SLIDING (P.slide_pp > 0): consecutive windows of a chunk share w - inc of their w bases, so the order-K table of window
+    // j + 1 is the table of window j minus the max-mers that start in its first inc positions plus those that start in the
+    // inc positions before the new window's last K - 1 - 2 inc updates spread over all threads (slide_pp positions of each
+    // range per thread) instead of w - K + 1 and a cleared table.  A counter word is a plain 32-bit sum of its fields' terms,
+    // so additions and subtractions commute mod 2^32: the word holds sum(count_f << BITS f) mod 2^32 whatever the order of the
+    // updates, which IS the packed counts whenever every count of the window fits its field - a window with a wrapped field is
+    // caught by the grand-total test as before (and handed on), and the table is right again as soon as the counts fit again.
+    // Everything else of a window - composition, short words, orphans, stages 3 and 4 - is computed as before, by the same
+    // lanes in the same order: rows do not depend on whether a window was slid into or counted afresh.
+    const int slide_pp = P.in_list == nullptr ? P.slide_pp : 0;
+    bool slide_next = false;            // the table is left standing for the next window (which slides); false: it is cleared
 #ifdef FRISK_STAMPS
     int stamp_win = -1;         // (diagnostic builds: STAMP of scan_kernel.h - wave 0 of the first workgroups, s_memtime per stage)
 #endif
@@ -277,6 +303,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             window_of(cand, st, rep_start, rep_stop, n, jump);
             const int64_t g0 = d.off + (st - d.base0);            // resident position of the window's first base
             const int64_t row = cand - P.c0;
+            // this window slides into the table its predecessor left; its successor - the next candidate of this chunk, in the
+            // same scaffold, a full window like this one (no jumpback, L230-232) - will slide into this one's
+            const bool sliding = slide_next;
+            slide_next = slide_pp > 0 && ci + 1 < ce && d.kind == 0 && !jump && cand + 1 < d.cand0 + d.ncand &&
+                         st + int64_t(P.inc) + P.w <= d.size;
             if (n > NT * ITS) {
                 // a rescued small scaffold (--scaffoldsAll, L211-221: up to 1.75 w bases) longer than this kernel's lanes cover:
                 // straight to the wider forms - per WINDOW, so that which kernel scores a window never depends on what else
@@ -298,6 +329,33 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // (all seven words requested before the first is used: one round trip to L2 / HBM, not two)
             const uint32_t w0 = P.codes[wi], w1 = P.codes[wi + 1], w2 = P.codes[wi + 2];
             const uint32_t i0 = P.inv[mi], i1 = P.inv[mi + 1], l0 = P.low[mi], l1 = P.low[mi + 1];
+            // sliding: the thread's slide_pp positions of the range that leaves (the predecessor's first inc positions) and of
+            // the range that enters (the inc positions before this window's last K - 1), requested with the words above
+            uint64_t scode = 0, ecode = 0;              // 32 bases from the thread's first position of either range
+            uint32_t sfull = 0, efull = 0;              // a max-mer starts at the thread's position it <-> bit 31 - it
+            if (sliding) {
+                const int q0 = tid * slide_pp;
+                const int cnt = P.inc - q0;             // the thread's positions: min(cnt, slide_pp), none if <= 0
+                const int64_t gs = g0 - P.inc + (cnt > 0 ? q0 : 0);
+                const int64_t ge = g0 + (P.w - (K - 1) - P.inc) + (cnt > 0 ? q0 : 0);
+                const int64_t swi = gs >> 4, smi = gs >> 5, ewi = ge >> 4, emi = ge >> 5;
+                const uint32_t s0 = P.codes[swi], s1 = P.codes[swi + 1], s2 = P.codes[swi + 2], si0 = P.inv[smi], si1 = P.inv[smi + 1];
+                const uint32_t e0 = P.codes[ewi], e1 = P.codes[ewi + 1], e2 = P.codes[ewi + 2], ei0 = P.inv[emi], ei1 = P.inv[emi + 1];
+                auto funnel = [](uint32_t a, uint32_t b, uint32_t c, int sh) -> uint64_t {
+                    return (uint64_t(uint32_t(((uint64_t(a) << 32) | b) >> sh)) << 32) | uint32_t(((uint64_t(b) << 32) | c) >> sh);
+                };
+                auto starts = [](uint32_t inv32, int cnt_, int pp) -> uint32_t {      // K valid bases from the position on
+                    uint32_t f = ~inv32;
+                    f &= f << 1; f &= f << 2;
+                    f &= f << (K - 4);
+                    const int m = cnt_ < pp ? cnt_ : pp;
+                    return m > 0 ? f & uint32_t(0xFFFFFFFF00000000ull >> m) : 0u;
+                };
+                scode = funnel(s0, s1, s2, 32 - int(gs & 15) * 2);
+                ecode = funnel(e0, e1, e2, 32 - int(ge & 15) * 2);
+                sfull = starts(uint32_t(((uint64_t(si0) << 32) | si1) >> (32 - int(gs & 31))), cnt, slide_pp);
+                efull = starts(uint32_t(((uint64_t(ei0) << 32) | ei1) >> (32 - int(ge & 31))), cnt, slide_pp);
+            }
             const uint32_t chi = uint32_t(((uint64_t(w0) << 32) | w1) >> shc);
             const uint32_t clo = uint32_t(((uint64_t(w1) << 32) | w2) >> shc);
             const uint64_t acode = (uint64_t(chi) << 32) | clo;             // bases j0 .. j0+31, first base in the top bits
@@ -359,12 +417,28 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 const uint32_t shortm = actm & ~fullm;                   // the lane's positions of that kind
                 const unsigned long long short_lanes = __ballot(shortm != 0u);
                 const bool few = __popcll(short_lanes) <= FRISK8_SHORT_LANES;
+                if (!sliding) {
 #pragma unroll FRISK8_UNROLL1
-                for (int it = 0; it < ITS; ++it) {
-                    const uint32_t bit = 0x80000000u >> it;
-                    const uint32_t c16 = code_at(it);
-                    if (fullm & bit) atomicAdd(&t8[c16 >> SHW], 1u << ((c16 & PERM) * BITS));
-                    else if (!few && (shortm & bit)) short_word(c16, (ainv >> (24 - it)) & 0xFFu, n - (j0 + it));
+                    for (int it = 0; it < ITS; ++it) {
+                        const uint32_t bit = 0x80000000u >> it;
+                        const uint32_t c16 = code_at(it);
+                        if (fullm & bit) atomicAdd(&t8[c16 >> SHW], 1u << ((c16 & PERM) * BITS));
+                        else if (!few && (shortm & bit)) short_word(c16, (ainv >> (24 - it)) & 0xFFu, n - (j0 + it));
+                    }
+                } else {
+                    // the table slides: slide_pp positions of the leaving and of the entering range per thread
+#pragma unroll 2
+                    for (int it = 0; it < slide_pp; ++it) {
+                        const uint32_t bit = 0x80000000u >> it;
+                        const uint32_t cs = uint32_t(scode >> (64 - 2 * K - 2 * it)) & (NK - 1u);
+                        const uint32_t cn = uint32_t(ecode >> (64 - 2 * K - 2 * it)) & (NK - 1u);
+                        if (sfull & bit) atomicSub(&t8[cs >> SHW], 1u << ((cs & PERM) * BITS));
+                        if (efull & bit) atomicAdd(&t8[cn >> SHW], 1u << ((cn & PERM) * BITS));
+                    }
+                    if (!few) {
+                        for (int it = 0; it < ITS; ++it)
+                            if (shortm & (0x80000000u >> it)) short_word(code_at(it), (ainv >> (24 - it)) & 0xFFu, n - (j0 + it));
+                    }
                 }
                 // Few lanes with such positions (a window's last lane: K-1 of them in a row; the edges of an invalid run): one
                 // pass per LANE with its positions spread over the wave's lanes, instead of one exec-masked pass per position
@@ -481,7 +555,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // a counter wrapped, or too many orphans: the next wider form (8-bit, then scan_kernel.h's 16-bit) redoes this window
             // from scratch
             auto hand_over = [&]() {
-                clear_t8();
+                if (!slide_next) clear_t8();
                 clear_small();
                 if (tid == 0) { const unsigned int slot = atomicAdd(P.out_count, 1u); P.out_list[slot] = cand; }
                 __syncthreads();
@@ -489,7 +563,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             if (wrapped) { hand_over(); continue; }
             if (!keep) {
                 // dropped by the N filter (the composition comes from popcounts of stage 1: reliable whatever the counters did)
-                if (CLEAR_ALL) clear_t8(); else zero_own();
+                if (!slide_next) { if (CLEAR_ALL) clear_t8(); else zero_own(); }
                 clear_small();
                 if (tid == 0) {
                     P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop;
@@ -535,20 +609,40 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             struct Fetched { double Ig, A5; uint32_t W5, c8, w7; uint4 w6; };
             auto fetch = [&](uint32_t c16) __attribute__((always_inline)) -> Fetched {
                 Fetched f;
+#ifdef FRISK8_EXP_IGMASK    // (experiment builds, wrong results: the genome-side gather confined to a small footprint)
+                f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + ((c16 & uint32_t(FRISK8_EXP_IGMASK)) << 3));
+#else
                 f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^K always
+#endif
                 if (BITS == 8) {        // the counter of code c is byte c of the table
                     f.c8 = t8b[c16];
                     f.w7 = *reinterpret_cast<const uint32_t*>(t8b + (c16 & ~3u));
                     f.w6 = *reinterpret_cast<const uint4*>(t8b + (c16 & ~15u));
-                } else {                // the four nibbles of the 7-mer c >> 2 are the 16 bits at byte 2 (c >> 2)
+                } else {                // the sixteen nibbles of the 6-mer c >> 4 are the 8 bytes at 8 (c >> 4)
                     f.c8 = 0;
-                    f.w7 = *reinterpret_cast<const uint16_t*>(t8b + ((c16 >> 2) << 1));
+#if FRISK8_W7_READ
+                    f.w7 = *reinterpret_cast<const uint16_t*>(t8b + ((c16 >> 2) << 1));        // the 7-mer's four nibbles, read on their own
+#else
+                    f.w7 = 0;
+#endif
+#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 2)
+                    const uint2 x = make_uint2(0x11111111u, c16 | 0x1111u);
+#else
                     const uint2 x = *reinterpret_cast<const uint2*>(t8b + ((c16 >> 4) << 3));
+#endif
                     f.w6 = make_uint4(x.x, x.y, 0u, 0u);
                 }
-                const Pre8* e = reinterpret_cast<const Pre8*>(lds + L::pre + __umul24(c16 >> 6, 12u));     // (one v_mul_u32_u24)
-                f.W5 = e->W;
-                f.A5 = e->A;
+#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 4)
+                if (true) { f.W5 = c16 | 1024u; f.A5 = double(c16 >> 6) + 1.0; } else
+#endif
+                if (FRISK8_PRE_SPLIT) {
+                    f.W5 = *reinterpret_cast<const uint32_t*>(lds + L::pre + NL * 8 + ((c16 >> 6) << 2));
+                    f.A5 = *reinterpret_cast<const double*>(lds + L::pre + ((c16 >> 6) << 3));
+                } else {
+                    const Pre8* e = reinterpret_cast<const Pre8*>(lds + L::pre + __umul24(c16 >> 6, 12u));     // (one v_mul_u32_u24)
+                    f.W5 = e->W;
+                    f.A5 = e->A;
+                }
                 return f;
             };
             // counts of the three top orders of the max-mer c16 as the order-K table holds them: without the orphans
@@ -558,8 +652,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     c7 = __builtin_amdgcn_sad_u8(f.w7, 0u, 0u);
                     c6 = __builtin_amdgcn_sad_u8(f.w6.x, 0u, __builtin_amdgcn_sad_u8(f.w6.y, 0u, __builtin_amdgcn_sad_u8(f.w6.z, 0u, __builtin_amdgcn_sad_u8(f.w6.w, 0u, 0u))));
                 } else {
-                    c8 = __builtin_amdgcn_ubfe(f.w7, (c16 & 3u) * 4u, 4u);
-                    c7 = __builtin_amdgcn_udot8(f.w7, 0x1111u, 0u, false);
+#if FRISK8_W7_READ
+                    const uint32_t w7 = f.w7;
+#else
+                    // the 7-mer's four nibbles are 16 of the 64 bits already here: one 64-bit shift instead of an LDS read of its own
+                    // (the dot product's 0x1111 ignores what the shift leaves above them)
+                    const uint32_t w7 = uint32_t(((uint64_t(f.w6.y) << 32) | f.w6.x) >> ((c16 & 12u) << 2));
+#endif
+                    c8 = __builtin_amdgcn_ubfe(w7, (c16 & 3u) * 4u, 4u);
+                    c7 = __builtin_amdgcn_udot8(w7, 0x1111u, 0u, false);
                     c6 = __builtin_amdgcn_udot8(f.w6.x, 0x11111111u, __builtin_amdgcn_udot8(f.w6.y, 0x11111111u, 0u, false), false);
                 }
             };
@@ -714,8 +815,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         A4 = __builtin_fma(cd * cd, rx[x], A4);
                     }
                     if constexpr (LV == 4) {
-                        pre[q4].A = A4;
-                        pre[q4].W = W4;
+                        put_pre(q4, A4, W4);
                     } else {
                         double A5[4];
                         uint32_t W5[4];
@@ -727,14 +827,21 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         }
                         if constexpr (FUSED) {          // (the four entries in the lane's rotated order)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) { Pre8* e = pre + 4 * q4 + j5[m]; e->A = A5[m]; e->W = W5[m]; }
+                            for (int m = 0; m < 4; ++m) put_pre(4 * q4 + j5[m], A5[m], W5[m]);
                         } else {
                             auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
                             auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
+                            if (FRISK8_PRE_SPLIT) {
+                                uint4* oa = reinterpret_cast<uint4*>(preA + 4 * q4);
+                                oa[0] = make_uint4(lo(A5[0]), hi(A5[0]), lo(A5[1]), hi(A5[1]));
+                                oa[1] = make_uint4(lo(A5[2]), hi(A5[2]), lo(A5[3]), hi(A5[3]));
+                                *reinterpret_cast<uint4*>(preW + 4 * q4) = make_uint4(W5[0], W5[1], W5[2], W5[3]);
+                            } else {
                             uint4* out = reinterpret_cast<uint4*>(pre + 4 * q4);        // four entries = 48 bytes, 16-byte aligned
                             out[0] = make_uint4(lo(A5[0]), hi(A5[0]), W5[0], lo(A5[1]));
                             out[1] = make_uint4(hi(A5[1]), W5[1], lo(A5[2]), hi(A5[2]));
                             out[2] = make_uint4(W5[2], lo(A5[3]), hi(A5[3]), W5[3]);
+                            }
                         }
                     }
                 } else {
@@ -751,8 +858,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                             W += (cx[x] & wm[x]) << (2 * x);                    // count * 4**x (L399-408)
                             A = __builtin_fma(cd * cd, rx[x], A);               // w_x * p_x = c^2 4^x / D_x
                         }
-                        pre[c].A = A;
-                        pre[c].W = W;
+                        put_pre(c, A, W);
                     }
                 }
             }
@@ -812,7 +918,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             auto score_one = [&](const Fetched& f, uint32_t c8, uint32_t c7, uint32_t c6, uint32_t sel, bool on)
                                  __attribute__((always_inline)) {
                 double2 rs;                                                   // {1/c8 (1.0 for the 19 in 20 max-mers seen once), c8^2 r8}
+#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 8)
+                if constexpr (BITS == 4) rs = make_double2(1.0, r8 * double(sel & 15u));
+#else
                 if constexpr (BITS == 4) rs = rstab[sel & 15u];
+#endif
                 else {
                     rs = make_double2(rctab[sel & 15u], double(__umul24(sel, sel)) * r8);     // (the same product, rounded alike)
                     if (__builtin_expect(__any(c8 >= 16u), 0)) {              // (wave-uniform, rare: low-complexity sequence)
@@ -850,7 +960,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // code variants of stage 1 alive across the whole window (60 registers) instead of re-deriving them here
             uint32_t ah = uint32_t(acode >> 32), al = uint32_t(acode), fm4 = fullm;
             asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
-            const uint64_t acode4 = (uint64_t(ah) << 32) | al;
+            uint64_t acode4 = (uint64_t(ah) << 32) | al;
             auto raw4_at = [&](int it) -> uint32_t { return uint32_t(acode4 >> (64 - 2 * K - 2 * it)) & (NK - 1u); };
             // Shape of the scoring loop, measured per K (bench shard / C2 shape, M windows/s):
             //   K = 8 (LDS allows 3 / 2 workgroups per CU): unrolled, groups of 2: 44.8 / 36.2; rolled, groups of 1: 43.2 / 35.6
@@ -943,11 +1053,20 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             using orph2 = std::integral_constant<int, 2>;
             using orph4 = std::integral_constant<int, 4>;
             using orphN = std::integral_constant<int, 0>;
+#ifdef FRISK8_S4_REPEAT      // (experiment builds: the scoring loop 0 / 2 / 3 times - what a window costs without it, and what one more costs)
+#pragma unroll 1
+            for (int rep = 0; rep < FRISK8_S4_REPEAT; ++rep) {
+                asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
+                acode4 = (uint64_t(ah) << 32) | al;
+#endif
             if (n_orph <= 2 && n7 <= 1) {       // (every window without invalid bases)
                 if (__all(fm4 == ALL_MINE)) score_all(std::true_type{}, orph2{});
                 else score_all(std::false_type{}, orph2{});
             } else if (n_orph <= 4) score_all(std::false_type{}, orph4{});
             else score_all(std::false_type{}, orphN{});
+#ifdef FRISK8_S4_REPEAT
+            }
+#endif
 
             // workgroup totals in a fixed order: DPP butterfly per wave, then the NW partials in wave order
 #if FRISK8_PRIO
@@ -960,11 +1079,13 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             STAMP(7)
             // behind the barrier: nobody reads the tables any more.  The whole order-K table in 16-byte stores (8 / 16 per thread at
             // K = 8) is cheaper than every position clearing its own dword (20 tests, extracts and masked 4-byte stores per lane)
-            if constexpr (CLEAR_ALL) clear_t8();
-            else {
+            if (!slide_next) {          // (a successor that slides takes the table as it stands)
+                if constexpr (CLEAR_ALL) clear_t8();
+                else {
 #pragma unroll 4
-                for (int it = 0; it < ITS; ++it)
-                    if (fm4 & (0x80000000u >> it)) t8[raw4_at(it) >> SHW] = 0u;
+                    for (int it = 0; it < ITS; ++it)
+                        if (fm4 & (0x80000000u >> it)) t8[raw4_at(it) >> SHW] = 0u;
+                }
             }
             clear_small();
             if (tid == 0) {

@@ -1,7 +1,9 @@
 // synth_kernel.h - synthetic scaffolds generated on the device (bench / property tests).
 //
 // "Synthetic scaffolds of the named shape" (BASELINE.json): order-3 Markov background, compositional
-// islands drawn from a second, more skewed table, runs of N at two scales and soft-masked runs.  Every
+// islands drawn from a second, more skewed table, runs of N at two scales, soft-masked runs and - the "repeats"
+// shape - simple repeats at a primate-like density: poly-A / poly-T tails and short-period microsatellites, soft-masked
+// as RepeatMasker / TRF leave them in a released assembly (these are what makes an 8-mer occur 16+ times in 5 kb).  Every
 // property of a base is a pure function of (seed, scaffold index, position), so generation is parallel
 // over 4096-base blocks and frisk_amd/synth.py reproduces the same bytes on the host with numpy.
 #pragma once
@@ -13,7 +15,25 @@
 #define SYNTH_NBIG_BLOCKS 8        // large N runs: units of 8 blocks (32 768 bases)
 #define SYNTH_NSMALL 1024          // small N runs: units of 1 024 bases
 #define SYNTH_LOWER 512            // soft-masked runs: units of 512 bases
+#define SYNTH_REP 512              // simple repeats: at most one per unit of 512 bases, 12 .. 91 bases long
 #define SYNTH_GOLDEN 0x9E3779B97F4A7C15ull
+
+// the simple repeat of one 512-base unit, if it has one: start (absolute position), length and motif - a pure function of the
+// unit's hash.  Motifs (period, bases as 2-bit digits A=0,T=1,G=2,C=3): poly-A x3, poly-T x2, (CA)n, (TG)n, (AAAT)n.
+struct SynthRepeat { int64_t start; int32_t len, period; uint32_t motif; };
+__host__ __device__ inline SynthRepeat synth_repeat_of(uint32_t h, int64_t unit) {
+    SynthRepeat r;
+    r.len = 12 + int32_t((h >> 3) % 20u) + ((((h >> 8) & 3u) == 0u) ? int32_t((h >> 12) % 60u) : 0);
+    r.start = unit * SYNTH_REP + int64_t((h >> 20) % uint32_t(SYNTH_REP - 96));
+    const uint32_t kind = h & 7u;
+    r.period = kind < 5u ? 1 : (kind < 7u ? 2 : 4);
+    r.motif = kind < 3u ? 0x0u : (kind < 5u ? 0x1u : (kind == 5u ? 0xCu /* C,A */ : (kind == 6u ? 0x6u /* T,G */ : 0x01u /* A,A,A,T */)));
+    return r;
+}
+__host__ __device__ inline uint32_t synth_repeat_base(const SynthRepeat& r, int64_t p) {
+    const int32_t k = int32_t((p - r.start) % r.period);
+    return (r.motif >> (2 * (r.period - 1 - k))) & 3u;
+}
 
 struct SynthTables {
     uint32_t bg[64][4];            // cumulative 32-bit thresholds per order-3 context
@@ -59,7 +79,7 @@ inline void synth_make_tables(uint64_t seed, SynthTables& T) {
 // one thread per 4096-base block of one scaffold
 __global__ __launch_bounds__(64) void synth_kernel(uint8_t* __restrict__ out, int64_t len, uint64_t seed, uint32_t scaf,
                                                     const SynthTables T, uint32_t thr_island, uint32_t thr_nbig,
-                                                    uint32_t thr_nsmall, uint32_t thr_low) {
+                                                    uint32_t thr_nsmall, uint32_t thr_low, uint32_t thr_rep) {
     const int64_t nblk = (len + SYNTH_BLOCK - 1) / SYNTH_BLOCK;
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t blk = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; blk < nblk; blk += stride) {
@@ -69,19 +89,25 @@ __global__ __launch_bounds__(64) void synth_kernel(uint8_t* __restrict__ out, in
         uint32_t ctx = 0;
         const int64_t base = blk * SYNTH_BLOCK;
         const int64_t end = (base + SYNTH_BLOCK < len) ? base + SYNTH_BLOCK : len;
-        bool nsmall = false, lowr = false;
+        bool nsmall = false, lowr = false, rep = false;
+        SynthRepeat R;
+        R.start = 0; R.len = 0; R.period = 1; R.motif = 0;
         for (int64_t p = base; p < end; ++p) {
             if ((p & (SYNTH_LOWER - 1)) == 0 || p == base) {
                 nsmall = synth_unit_hash(seed, scaf, uint64_t(p / SYNTH_NSMALL), 3) < thr_nsmall;
                 lowr = synth_unit_hash(seed, scaf, uint64_t(p / SYNTH_LOWER), 4) < thr_low;
+                rep = thr_rep != 0u && synth_unit_hash(seed, scaf, uint64_t(p / SYNTH_REP), 5) < thr_rep;
+                if (rep) R = synth_repeat_of(synth_unit_hash(seed, scaf, uint64_t(p / SYNTH_REP), 6), p / SYNTH_REP);
             }
             state += SYNTH_GOLDEN;
             const uint32_t r = uint32_t(synth_mix(state) >> 32);
             const uint32_t* row = island ? T.isl[ctx] : T.bg[ctx];
-            const uint32_t b = (r >= row[0]) + (r >= row[1]) + (r >= row[2]);
+            uint32_t b = (r >= row[0]) + (r >= row[1]) + (r >= row[2]);
+            const bool in_rep = rep && p >= R.start && p < R.start + R.len;
+            if (in_rep) b = synth_repeat_base(R, p);
             ctx = ((ctx << 2) | b) & 63u;
             uint8_t ch = uint8_t("ATGC"[b]);
-            if (lowr) ch |= 0x20;
+            if (lowr || in_rep) ch |= 0x20;
             if (nbig || nsmall) ch = 'N';
             out[p] = ch;
         }

@@ -184,11 +184,11 @@ class Engine:
         names = [self._lib.frisk_seq_name(self._ctx, i).decode("ascii", "replace") for i in range(self.n_seq)]
         return names, (int(c0.value), int(c1.value))
 
-    def synth(self, lens, seed, island_frac=0.02, n_frac=0.0, lower_frac=0.0):
+    def synth(self, lens, seed, island_frac=0.02, n_frac=0.0, lower_frac=0.0, repeats_per_kb=0.0):
         lens = [int(x) for x in lens]
         arr = (C.c_int64 * max(len(lens), 1))(*lens)
         self._check(self._lib.frisk_seq_synth(self._ctx, arr, len(lens), C.c_uint64(seed), float(island_frac),
-                                              float(n_frac), float(lower_frac)))
+                                              float(n_frac), float(lower_frac), float(repeats_per_kb)))
         self.n_seq = len(lens)
         self.seq_lens = lens
 
@@ -260,11 +260,12 @@ class Engine:
         self._check(self._lib.frisk_scan_plan(self._ctx, int(w), int(inc), flags, C.byref(n)))
         return int(n.value)
 
-    def scan(self, w, inc, rip=False, scaffolds_all=False, c0=0, c1=-1, debug=False, pinned=False):
-        """Score candidates [c0, c1).  With pinned=True the result arrays are views of page-locked buffers owned
+    def scan(self, w, inc, rip=False, scaffolds_all=False, c0=0, c1=-1, debug=False, pinned=False, chunks=False):
+        """Score candidates [c0, c1).  chunks=True: the schedule of a long scan (chunks of 8 windows, tables sliding inside a
+        chunk) whatever the size - same rows.  With pinned=True the result arrays are views of page-locked buffers owned
         by the engine: D2H at PCIe rate and no per-call allocation, but the views are only valid until the next
         scan() on this engine.  pinned=False (default) returns ordinary numpy arrays."""
-        flags = (_ffi.SCAN_RIP if rip else 0) | (_ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0)
+        flags = (_ffi.SCAN_RIP if rip else 0) | (_ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0) | (_ffi.SCAN_CHUNKS if chunks else 0)
         total = self.scan_plan(w, inc, scaffolds_all)
         if c1 < 0:
             c1 = total

@@ -9,6 +9,9 @@ bytes: every property of a base is a pure function of (seed, scaffold index, pos
   * N runs    : units of 8 blocks (32 768 bases) with probability 0.8*n_frac, units of 1024 bases with
                 probability 0.2*n_frac
   * soft mask : units of 512 bases are lower-cased with probability lower_frac
+  * repeats   : units of 512 bases hold one simple repeat (poly-A x3 / poly-T x2 / (CA)n / (TG)n / (AAAT)n, 12..31 bases,
+                one in four up to 91) with probability repeats_per_kb * 0.512; soft-masked.  REPEATS_HG38 below is the
+                "realistic" shape of the bench: what a released primate assembly looks like to the counter widths
 """
 import numpy as np
 
@@ -17,6 +20,9 @@ ISLAND_BLOCKS = 5
 NBIG_BLOCKS = 8
 NSMALL = 1024
 LOWER = 512
+REP = 512
+# the bench's second shape: one simple repeat per ~3 kb (Alu poly-A tails + microsatellites), 45 % soft-masked, 7 % N
+REPEATS_HG38 = dict(island_frac=0.02, n_frac=0.07, lower_frac=0.45, repeats_per_kb=0.35)
 GOLDEN = np.uint64(0x9E3779B97F4A7C15)
 _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
@@ -60,13 +66,37 @@ def make_tables(seed):
     return bg, isl
 
 
-def scaffold(length, seed, scaf_index, island_frac=0.02, n_frac=0.0, lower_frac=0.0):
+def _repeats(length, seed, scaf_index, repeats_per_kb):
+    """(in_repeat mask, repeat base digit) per position - synth_repeat_of / synth_repeat_base of csrc/synth_kernel.h."""
+    pos = np.arange(length, dtype=np.int64)
+    unit = pos // REP
+    thr = frac_to_u32(repeats_per_kb * (REP / 1000.0))
+    if thr == 0:
+        return np.zeros(length, bool), np.zeros(length, np.int64)
+    nunit = int(unit[-1]) + 1
+    u = np.arange(nunit, dtype=np.uint64)
+    on = _unit_hash(seed, scaf_index, u, 5) < np.uint32(thr)
+    h = _unit_hash(seed, scaf_index, u, 6).astype(np.int64)
+    ln = 12 + (h >> 3) % 20 + np.where(((h >> 8) & 3) == 0, (h >> 12) % 60, 0)
+    start = np.arange(nunit, dtype=np.int64) * REP + (h >> 20) % (REP - 96)
+    kind = h & 7
+    period = np.where(kind < 5, 1, np.where(kind < 7, 2, 4))
+    motif = np.where(kind < 3, 0x0, np.where(kind < 5, 0x1, np.where(kind == 5, 0xC, np.where(kind == 6, 0x6, 0x01))))
+    inside = on[unit] & (pos >= start[unit]) & (pos < start[unit] + ln[unit])
+    k = (pos - start[unit]) % period[unit]
+    base = (motif[unit] >> (2 * (period[unit] - 1 - k))) & 3
+    return inside, base
+
+
+def scaffold(length, seed, scaf_index, island_frac=0.02, n_frac=0.0, lower_frac=0.0, repeats_per_kb=0.0):
     """bytes of one synthetic scaffold (vectorised over its 4096-base blocks)."""
     length = int(length)
     if length <= 0:
         return b""
     bg, isl = make_tables(seed)
     nblk = (length + BLOCK - 1) // BLOCK
+    in_rep, rep_base = _repeats(nblk * BLOCK, seed, scaf_index, repeats_per_kb)
+    in_rep, rep_base = in_rep.reshape(nblk, BLOCK), rep_base.reshape(nblk, BLOCK)
     blk = np.arange(nblk, dtype=np.uint64)
     island = _unit_hash(seed, scaf_index, blk // np.uint64(ISLAND_BLOCKS), 1) < np.uint32(frac_to_u32(island_frac))
     key = (np.uint64(scaf_index) << np.uint64(40)) ^ blk
@@ -82,12 +112,13 @@ def scaffold(length, seed, scaf_index, island_frac=0.02, n_frac=0.0, lower_frac=
             r = (_mix(state) >> np.uint64(32)).astype(np.uint32)
             row = tab[rows, ctx]                                        # (nblk, 4)
             b = (r >= row[:, 0]).astype(np.int64) + (r >= row[:, 1]) + (r >= row[:, 2])
+            b = np.where(in_rep[:, t], rep_base[:, t], b)
             ctx = ((ctx << 2) | b) & 63
             out[:, t] = letters[b]
     seq = out.reshape(-1)[:length].copy()
     pos = np.arange(length, dtype=np.uint64)
     low = _unit_hash(seed, scaf_index, pos // np.uint64(LOWER), 4) < np.uint32(frac_to_u32(lower_frac))
-    seq[low] |= 0x20
+    seq[low | in_rep.reshape(-1)[:length]] |= 0x20
     nbig = _unit_hash(seed, scaf_index, pos // np.uint64(BLOCK * NBIG_BLOCKS), 2) < np.uint32(frac_to_u32(n_frac * 0.8))
     nsmall = _unit_hash(seed, scaf_index, pos // np.uint64(NSMALL), 3) < np.uint32(frac_to_u32(n_frac * 0.2))
     seq[nbig | nsmall] = ord("N")

@@ -41,6 +41,9 @@ enum {
 /* frisk_scan flags */
 #define FRISK_SCAN_RIP           1u   /* fill pi/si/cri (--RIP, L1485-1486); needs kmin <= 2 <= kmax  */
 #define FRISK_SCAN_SCAFFOLDS_ALL 2u   /* --scaffoldsAll: small scaffolds become one window (L211-221) */
+#define FRISK_SCAN_CHUNKS       256u /* schedule the windows in chunks of 8 consecutive candidates whatever the scan's size (a short
+                                        scan is otherwise dealt window by window): the path long scans take - tables sliding from
+                                        window to window inside a chunk - on inputs of any size.  Results are the same bits. */
 
 /* per-row status bits written to `status` by frisk_scan */
 #define FRISK_ROW_KEPT        1u      /* window passed the < 30 % non-ACGT filter (L237-241)          */
@@ -71,8 +74,10 @@ int frisk_seq_load(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* le
 /* Double-buffered residency - the "streamed to HBM" of the north star.  frisk_seq_stage uploads and packs the NEXT batch on
  * a second HIP stream while the resident batch is being profiled / scanned; frisk_seq_commit makes it the resident batch
  * (the compute stream waits for the upload on the device, the host does not block).  The copies are asynchronous when the
- * source buffers are page-locked (frisk_host_alloc); the caller keeps them alive until the next synchronising call
- * (frisk_scan, frisk_profile_add, ...) after the commit.  frisk_seq_stage_packed takes the three bit-packed arrays in the
+ * source buffers are page-locked (frisk_host_alloc); the caller keeps them alive until the next call after the commit that
+ * synchronises with the device - frisk_scan, frisk_profile_get, frisk_profile_export_host, frisk_seq_export_packed,
+ * frisk_seq_read (frisk_profile_reset / _add / _finalize only enqueue).  A stage also waits, on the device, for work
+ * queued before the last commit: the slot it fills may still be read by that work.  frisk_seq_stage_packed takes the three bit-packed arrays in the
  * library's own layout (as frisk_seq_export_packed returns them for the same `lens`): 0.5 bytes per base over PCIe instead
  * of 1, and no parsing - the sequence-cache path of the CLI. */
 int frisk_seq_stage(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq);
@@ -106,10 +111,11 @@ const char* frisk_seq_name(const frisk_ctx* ctx, int32_t seq_index);   /* "" for
 int64_t frisk_seq_len(const frisk_ctx* ctx, int32_t seq_index);
 
 /* Bench/test utility: fill the resident batch with synthetic scaffolds generated ON the device
- * (order-3 Markov background + compositional islands + N runs + soft-masked runs; the generator
- * is specified in frisk_amd/synth.py, which reproduces it bit-for-bit on the host). */
+ * (order-3 Markov background + compositional islands + N runs + soft-masked runs + simple repeats - poly-A / poly-T
+ * tails and microsatellites, repeats_per_kb of them per 1000 bases, soft-masked; the generator is specified in
+ * frisk_amd/synth.py, which reproduces it bit-for-bit on the host). */
 int frisk_seq_synth(frisk_ctx* ctx, const int64_t* lens, int32_t n_seq, uint64_t seed,
-                    double island_frac, double n_frac, double lower_frac);
+                    double island_frac, double n_frac, double lower_frac, double repeats_per_kb);
 
 /* Copy bases [offset, offset+n) of resident scaffold seq_index back as ASCII (canonical letters:
  * A/T/G/C, a/t/g/c, N for every non-ACGT letter) - test / bench-sampling utility. */

@@ -1,0 +1,109 @@
+"""The sliding order-K table (scan8_kernel.h: inside a chunk of 8 consecutive windows the table of window j + 1 is the
+table of window j minus the max-mers that leave plus those that enter) against the compiled CPU oracle and against the
+same scan with every window counted afresh - the SAME BITS in every column, KLD included: what a window reads from the
+table, and the order in which its terms are summed, do not depend on how the table came about.
+
+FRISK_SCAN_CHUNKS (Engine.scan(chunks=True)) gives small inputs the schedule of a long scan; without it a scan of fewer
+than ~12 000 windows is dealt window by window and nothing slides."""
+import numpy as np
+import pytest
+
+from frisk_amd import _ffi
+from frisk_amd.engine import Engine
+from oracle import frisk_oracle_c as OC
+
+pytestmark = pytest.mark.gpu
+
+COLS = ("seq_index", "start", "stop", "status", "kld", "gc")
+
+
+def _same_bits(a, b, rip, tag):
+    assert len(a) == len(b), tag
+    for col in COLS + (("pi", "si", "cri") if rip else ()):
+        x, y = getattr(a, col), getattr(b, col)
+        keep = a.kept if col not in ("seq_index", "start", "stop", "status") else slice(None)
+        assert np.array_equal(x[keep].view(np.uint64 if x.dtype.itemsize == 8 else x.dtype),
+                              y[keep].view(np.uint64 if y.dtype.itemsize == 8 else y.dtype)), (tag, col)
+
+
+def _against_oracle(res, c, tag):
+    osym, ometa = OC.genome_profile(c["seqs"], c["kmin"], c["kmax"], False)
+    ig = OC.genome_ivom(osym, ometa, c["kmin"], c["kmax"])
+    exp = OC.scan(c["seqs"], ig, c["kmin"], c["kmax"], c["w"], c["inc"], scaffolds_all=c["scaffolds_all"], rip=c["rip"])
+    k = np.nonzero(res.kept)[0]
+    assert len(k) == len(exp["kld"]), tag
+    if not len(k):
+        return 0
+    assert np.array_equal(res.seq_index[k], exp["seq"]) and np.array_equal(res.start[k], exp["start"]), tag
+    assert np.array_equal(res.stop[k], exp["stop"]) and np.array_equal(res.gc[k], exp["gc"], equal_nan=True), tag
+    zero = (exp["status"] & OC.ROW_ZERO_DIV) != 0
+    assert np.array_equal((res.status[k] & _ffi.ROW_ZERO_WEIGHT) != 0, zero), tag
+    if c["rip"]:
+        for col in ("pi", "si", "cri"):
+            assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True), tag
+    ok = ~zero
+    if ok.any():
+        assert np.max(np.abs(res.kld[k][ok] - exp["kld"][ok])) <= 1e-11, tag
+    return len(k)
+
+
+def _case(rng):
+    kmax = int(rng.choice([6, 7, 8, 8, 8]))
+    kmin = int(rng.integers(1, kmax - 2))              # the narrow-counter kernels: kmin <= K - 3
+    w = int(rng.choice([600, 1000, 2000, 2048, 3001, 5000, 5120]))
+    inc = max(1, int(w * rng.choice([0.013, 0.05, 0.1, 0.2, 0.25, 0.4, 0.49, 0.5])))
+    seqs = []
+    for _ in range(int(rng.integers(1, 5))):
+        n = int(rng.choice([w // 2, w + inc, 3 * w, 9 * inc + w + int(rng.integers(0, inc + 1)), 30 * inc + w, 70 * inc + 17]))
+        p = rng.dirichlet([2, 2, 2, 2])
+        s = rng.choice(np.frombuffer(b"ATGC", dtype=np.uint8), size=n, p=p)
+        for _ in range(int(rng.integers(0, 8))):
+            a = int(rng.integers(0, n))
+            ln = int(rng.choice([1, 2, 7, 8, 9, 40, inc, w // 3 + 1, w]))
+            kind = rng.integers(0, 5)
+            if kind == 0:
+                s[a:a + ln] = ord("N")
+            elif kind == 1:
+                s[a:a + ln] |= 0x20
+            elif kind == 2:
+                s[a:a + ln] = rng.choice(np.frombuffer(b"RYKMnrx-*", dtype=np.uint8), size=len(s[a:a + ln]))
+            elif kind == 3:
+                s[a:a + ln] = s[a]                                             # poly-X: wraps 4- and 8-bit counters
+            else:
+                unit = rng.choice(np.frombuffer(b"ATGC", dtype=np.uint8), size=int(rng.integers(2, 5)))
+                s[a:a + ln] = np.resize(unit, len(s[a:a + ln]))                # a microsatellite
+        seqs.append(s.tobytes())
+    return dict(kmin=kmin, kmax=kmax, w=w, inc=inc, seqs=seqs, scaffolds_all=bool(rng.integers(0, 2)),
+                rip=bool(rng.integers(0, 2)) and kmin <= 2)
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_sliding_tables_equal_fresh_counts_and_the_oracle(block):
+    rng = np.random.default_rng(7300 + block)
+    checked = slid = 0
+    for case_no in range(16):
+        c = _case(rng)
+        tag = "block %d case %d: k=%d..%d w=%d i=%d all=%s rip=%s lens=%s" % (
+            block, case_no, c["kmin"], c["kmax"], c["w"], c["inc"], c["scaffolds_all"], c["rip"], [len(s) for s in c["seqs"]])
+        with Engine(c["kmin"], c["kmax"]) as e:
+            e.load(c["seqs"])
+            e.profile_reset(); e.profile_add(); e.profile_finalize()
+            fresh = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"])
+            chunked = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"], chunks=True)
+            n = len(fresh)
+            _same_bits(fresh, chunked, c["rip"], tag)
+            if n > 12:       # another range: the chunks start elsewhere, other windows are slid into
+                c0 = int(rng.integers(1, 8))
+                part = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"], c0=c0, c1=n - 1, chunks=True)
+                for col in COLS:
+                    x, y = getattr(part, col), getattr(fresh, col)[c0:n - 1]
+                    assert np.array_equal(x.view(np.uint64 if x.dtype.itemsize == 8 else x.dtype),
+                                          y.view(np.uint64 if y.dtype.itemsize == 8 else y.dtype), ), (tag, col, "range")
+            if case_no % 4 == 0 and n <= 400:      # the count tables themselves, window by window
+                dbg_f = e.scan(c["w"], c["inc"], scaffolds_all=c["scaffolds_all"], debug=True)
+                dbg_c = e.scan(c["w"], c["inc"], scaffolds_all=c["scaffolds_all"], debug=True, chunks=True)
+                k = dbg_f.kept
+                assert np.array_equal(dbg_f.counts[k], dbg_c.counts[k]) and np.array_equal(dbg_f.meta[k], dbg_c.meta[k]), tag
+        checked += _against_oracle(chunked, c, tag)
+        slid += 2 * c["inc"] <= c["w"] - (c["kmax"] - 1)
+    assert checked > 150 and slid >= 8

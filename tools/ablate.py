@@ -21,7 +21,7 @@ e.synth(lens, seed=0xC5, island_frac=0.02, n_frac=0.07)
 e.profile_reset(); e.profile_add(); e.profile_finalize()
 ts = []
 for _ in range(4):
-    r = e.scan(5000, 1000); ts.append(e.kernel_ms(0))
+    r = e.scan(5000, 1000, pinned=True); ts.append(e.kernel_ms(0))
 e.profile_reset(); e.profile_add(); tp = e.kernel_ms(1)
 print(json.dumps({"scan_ms": min(ts), "profile_ms": tp, "cands": r.n_candidates, "kld_sum": float(r.kld[r.kept].sum())}))
 '''
