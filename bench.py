@@ -18,6 +18,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     - HBM roofline of the dominant kernel (scan): algorithmic bytes / HIP-event kernel time; `traffic`
                  and the `binding` block (what actually binds: VALU issue, LDS, waits) come from rocprofv3 PMC passes
                  of the same workload collected OFFLINE and committed under profiles/ (named in the line)
+  cold         - the FIRST step on a freshly resident batch (the adaptive counter width's 1/16 sample and its host sync are
+                 paid there; the timed steps of `value` rescan a resident batch and reuse the sample's verdict)
+  strong       - the WHOLE C5 shape (3.29 Gb, 3.06 M rows) as one job split over the N ranks (N = 1: all of it on one GPU):
+                 the strong-scaling anchor beside the weak-scaling `value`
+  realistic    - the same shard with simple repeats at a primate-like density (poly-A/T tails, microsatellites), unmasked and
+                 soft-masked: the counter widths real assemblies take, first (cold) step included
   upload       - the same job including host -> HBM: one job from page-locked ASCII, one from the
                  0.5 B/base packed form, and the steady state with the next batch's upload overlapped (N = 1 only)
   cpu_baseline - the reference-shaped Python oracle timed on one host core on a bounded sample
@@ -173,6 +179,103 @@ def upload_inclusive(eng, lens, step, fence, steps, rows):
                    "scored, so a single job pays upload + scan; a stream of batches hides the upload behind the previous scan")
     return out
 
+def csrc_hash():
+    """sha256 over the library's sources (frisk_amd/csrc/*, include/*.h): a profile of the scan kernel is only quoted for the
+    sources it was taken from (tools/pmc_bench_json.py stamps the same hash into profiles/*_pmc_bench.json)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "frisk_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def timed_steps(step, fence, warmup, steps):
+    """(seconds per step, last result, kernel times) - barrier + synchronize on both sides, as the headline loop."""
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    scan_ms = []
+    for _ in range(steps):
+        res, _tp, ts = step()
+        scan_ms.append(ts)
+    fence()
+    return (time.perf_counter() - t0) / steps, res, sum(scan_ms) / len(scan_ms)
+
+
+def cold_step(eng, synth_args, step, fence):
+    """One step on a batch that has just become resident (re-generated: any per-batch state of the library is gone): the
+    adaptive counter width runs its 1/16 sample, with a host synchronisation, inside this step."""
+    lens, kw = synth_args
+    eng.synth(lens, **kw)
+    fence()
+    t0 = time.perf_counter()
+    res, _tp, ts = step()
+    fence()
+    return (time.perf_counter() - t0) * 1e3, ts, res
+
+
+def shape_block(eng, lens, kw, step, fence, steps, label):
+    """One more shape on the same shard: cold first step, then warm steps."""
+    import numpy as np
+    cold_ms, cold_scan_ms, _ = cold_step(eng, (lens, kw), step, fence)
+    dt, res, scan_ms = timed_steps(step, fence, 1, steps)
+    rows = int(res.kept.sum())
+    width, h8, h16, _seg = eng.scan_stat()
+    n = len(res)
+    return {"shape": label, "synth": {k: v for k, v in kw.items() if k != "seed"},
+            "value": rows / dt, "unit": "windows/s (emitted rows, as `value`)", "candidate_windows_per_s": n / dt,
+            "ms_per_step": dt * 1e3, "scan_kernel_ms": scan_ms, "rows": rows, "candidate_windows": n,
+            "share_of_candidates_kept": rows / max(n, 1),
+            "scan_counter_width": {"bulk_bits": width, "windows_handed_to_8bit": h8, "windows_handed_to_16bit": h16},
+            "cold_first_step_ms": cold_ms, "cold_first_scan_kernel_ms": cold_scan_ms,
+            "max_kld": float(np.nanmax(res.kld[res.kept])) if rows else None}
+
+
+def strong_block(eng, dist, torch, rank, world, local_seed, fence, steps):
+    """The whole C5 shape as ONE job over the N ranks: every rank holds the packed assembly (4.9 GB of 288), counts the k-mers
+    that start in its N-th of the positions, the raw profiles are summed by the one all-reduce, and every rank scores its N-th
+    of the candidate windows (contiguous ranges in output order; rows stay on the rank, as in the weak steps).  N = 1 is the
+    whole job on one GPU.  (The CLI's multi-GPU path shards the residency too - frisk_fasta_load_shard; here the point is the
+    time of the job against N.)"""
+    from frisk_amd import synth
+    lens = [n for r in range(8) for n in synth.c5_shard_lens(8, r)]
+    eng.synth(lens, seed=0xC5, island_frac=0.02, n_frac=0.07, lower_frac=0.0)
+    n_cand = eng.scan_plan(W, INC)
+    padded = eng.padded_len
+    c0, c1 = n_cand * rank // world, n_cand * (rank + 1) // world
+    p0, p1 = (padded // 32 * rank // world) * 32, (padded // 32 * (rank + 1) // world) * 32      # (whole 32-position words)
+    if rank == world - 1:
+        p1 = padded
+
+    def step():
+        eng.profile_reset()
+        eng.profile_add(mask_host=False, pos_begin=p0, pos_end=p1)
+        eng.profile_allreduce()
+        eng.profile_finalize()
+        res = eng.scan(W, INC, c0=c0, c1=c1, pinned=True)
+        return res, eng.kernel_ms(1), eng.kernel_ms(0)
+
+    dt, res, scan_ms = timed_steps(step, fence, 2, steps)
+    rows = int(res.kept.sum())
+    if dist is not None:
+        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, rows_all = float(tmax[0]), float(t[1])
+    else:
+        rows_all = float(rows)
+    return {"scaling": "strong", "value": rows_all / dt, "unit": "windows/s", "ms_per_step": dt * 1e3,
+            "workload": "whole C5 shape: %d scaffolds, %d bases, %d candidate windows, %d rows; rank r scores candidates "
+                        "[n r / N, n (r + 1) / N) and counts the k-mers starting in its N-th of the positions; one all-reduce"
+                        % (len(lens), sum(lens), n_cand, int(rows_all)),
+            "bases": sum(lens), "candidate_windows": n_cand, "rows": int(rows_all), "gbases_per_s": sum(lens) / dt / 1e9,
+            "scan_kernel_ms_rank0": scan_ms}
+
 
 def self_launch(opts, argv):
     """--gpus N without a launcher: become the launcher (no GPU call has been made yet) and relay the ranks' output."""
@@ -197,6 +300,7 @@ def main(argv=None):
                     help="scale every scaffold length of the shard (testing only; 1.0 = the named workload)")
     ap.add_argument("--cpu-windows", type=int, default=150, help="windows in the CPU-baseline sample, ~0.1 s each (0 = skip)")
     ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cold / strong / realistic blocks (profiling runs)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (gloo, no GPU): proves the N-rank launch path; rank 0 prints {dry_run, world}")
     opts = ap.parse_args(argv)
@@ -276,6 +380,23 @@ def main(argv=None):
     else:
         rows_all, bases_all, cand_all = float(rows), float(total_bases), float(n_cand)
 
+    shard_kw = dict(seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0)
+    cold = strong = None
+    realistic = []
+    if not opts.no_extra:
+        few = max(2, min(opts.steps, 10))
+        cold_ms, cold_scan_ms, _ = cold_step(eng, (lens, shard_kw), step, fence)
+        cold = {"cold_first_step_ms": cold_ms, "cold_first_scan_kernel_ms": cold_scan_ms,
+                "note": "first step on a batch that has just become resident: includes the 1/16 sample of the adaptive counter "
+                        "width and its host synchronisation; the steps behind `value` reuse the sample's verdict"}
+        strong = strong_block(eng, dist, torch, rank, world, 0xC5, fence, few)
+        if world == 1:
+            for label, kw in (("unmasked assembly with simple repeats", synth.REPEATS_UNMASKED),
+                              ("soft-masked assembly with simple repeats", synth.REPEATS_SOFT)):
+                realistic.append(shape_block(eng, lens, dict(kw, seed=0xC5 + rank), step, fence, few, label))
+        eng.synth(lens, **shard_kw)         # the headline shard again (upload block, CPU baselines)
+        step()
+        fence()
     upload = None
     if world == 1 and not opts.no_upload:
         upload = upload_inclusive(eng, lens, step, fence, opts.steps, rows)
@@ -290,13 +411,19 @@ def main(argv=None):
         traffic, binding, pmc_src = None, None, None
         # HBM traffic and issue counters: rocprofv3 --pmc passes of THIS workload, collected offline (separate runs, never
         # combined with tracing) and committed; valid only for the same shard and the same kernel
-        tpath = os.path.join(ROOT, "profiles", "r2_pmc_bench.json")
+        tpath = os.path.join(ROOT, "profiles", "r3_pmc_bench.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("workload_bases_per_gpu") == total_bases and tj.get("candidate_windows_per_gpu") == n_cand:
-                pmc_src = "profiles/r2_pmc_bench.json (offline rocprofv3 --pmc passes of this workload; not measured in this run)"
+            same_work = tj.get("workload_bases_per_gpu") == total_bases and tj.get("candidate_windows_per_gpu") == n_cand
+            # ... and only for the SOURCES the profile was taken from: the file carries their hash and the profiled kernel's name
+            if same_work and tj.get("csrc_sha256") == csrc_hash():
+                pmc_src = ("profiles/r3_pmc_bench.json (offline rocprofv3 --pmc passes of this workload and of these sources - "
+                           "csrc_sha256 matches; kernel %s; not measured in this run)" % tj.get("kernel"))
                 traffic = tj.get("hbm_bytes_per_launch")
                 binding = tj.get("binding")
+            else:
+                pmc_src = ("profiles/r3_pmc_bench.json was taken from other sources or another workload (csrc_sha256 / sizes "
+                           "differ): traffic and binding not quoted")
         out = {
             "metric": "windows/sec (k=1..8, w=5kb, s=1kb)", "value": rows_all / (elapsed / opts.steps),
             "unit": "windows/s", "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
@@ -325,6 +452,9 @@ def main(argv=None):
                          "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
                                  "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding`"},
             "binding": binding,
+            "cold": cold,
+            "strong": strong,
+            "realistic": realistic,
             "upload": upload,
         }
         if opts.cpu_windows > 0:

@@ -223,7 +223,9 @@ def _main(argv=None):
     columns = _columns(args)
     rip = len(columns) == 8
     w, inc, all_ = args.windowlen, args.increment, bool(args.scaffoldsAll)
-    hp = HotPath(args.minWordSize, args.maxWordSize, device=local_rank)
+    # (the packed-sequence cache lives beside the pickle caches; --recalc - store_false - means: recompute, so rewrite it too)
+    hp = HotPath(args.minWordSize, args.maxWordSize, device=local_rank, cache_dir=None if sharded else args.tempDir,
+                 use_cache=bool(args.recalc))
     clock.lap("startup (imports + HIP context)")
     table = None
     try:
@@ -243,7 +245,7 @@ def _main(argv=None):
                 genomeKmers = hp.profileMaps() if rank == 0 else None
             else:
                 hp._load(args.hostSeq)
-                clock.lap("FASTA parse + upload + pack")
+                clock.lap("packed sequence cache -> HBM" if hp.loaded_from_cache else "FASTA parse + upload + pack")
                 genomeKmers = hp.genomeProfile(args)
             clock.lap("phase A (profile)" if not sharded else "phase A (parse + upload + profile + all-reduce)")
             if rank == 0:

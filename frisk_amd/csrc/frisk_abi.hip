@@ -334,10 +334,16 @@ hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const Sca
     if (bits == 4) {
         if (debug) { if (small_w) FRISK_L8(8, 4, 3, true); else FRISK_L8(20, 4, 3, true); }
         if (small_w) FRISK_L8(8, 4, 3, false);
+#ifdef FRISK8_NT512      // (experiment builds: 512-thread workgroups, three per CU = six waves per SIMD)
+        return launch_scan8<8, 512, 10, 4, 64, 6, false>(P, num_cu, work_items, st);
+#endif
         FRISK_L8(20, 4, 3, false);
     }
     if (debug) { if (small_w) FRISK_L8(8, 8, 2, true); else FRISK_L8(20, 8, 2, true); }
     if (small_w) FRISK_L8(8, 8, 2, false);
+#ifdef FRISK8_NT512_8    // (experiment builds: the 8-bit form with 512-thread workgroups, two per CU = four waves per SIMD)
+    return launch_scan8<8, 512, 10, 8, 32, 4, false>(P, num_cu, work_items, st);
+#endif
     FRISK_L8(20, 8, 2, false);
 #undef FRISK_L8
 }
@@ -751,9 +757,14 @@ int frisk_seq_stage_packed(frisk_ctx* c, const uint32_t* codes, const uint32_t* 
     rc = alloc_packed(c, B, c->copy_stream);
     if (rc) return rc;
     const size_t w32 = size_t(B.padded_len / 32);
-    HIPC(c, hipMemcpyAsync(B.d_codes.p, codes, 2 * w32 * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIPC(c, hipMemcpyAsync(B.d_inv.p, inv, w32 * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIPC(c, hipMemcpyAsync(B.d_low.p, low, w32 * 4, hipMemcpyHostToDevice, c->copy_stream));
+    // (h2d: page-locked sources asynchronously; pageable ones - the memory-mapped sequence cache - through the context's
+    //  page-locked pieces at PCIe rate instead of the runtime's own staging)
+    rc = h2d(c, B.d_codes.p, codes, 2 * w32 * 4, c->copy_stream);
+    if (rc) return rc;
+    rc = h2d(c, B.d_inv.p, inv, w32 * 4, c->copy_stream);
+    if (rc) return rc;
+    rc = h2d(c, B.d_low.p, low, w32 * 4, c->copy_stream);
+    if (rc) return rc;
     HIPC(c, hipEventRecord(c->staged_ev, c->copy_stream));
     c->staged = true;
     return FRISK_OK;
@@ -925,6 +936,13 @@ int frisk_profile_import_device(frisk_ctx* c, const void* src) {
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemcpyAsync(c->d_raw.p, src, (size_t(c->nprof) + 4) * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    c->profile_final = false;
+    return FRISK_OK;
+}
+int frisk_profile_device_view(frisk_ctx* c, void** raw, void** stream) {
+    if (!c || !raw || !stream) return FRISK_E_ARG;
+    *raw = c->d_raw.p;
+    *stream = reinterpret_cast<void*>(c->stream);
     c->profile_final = false;
     return FRISK_OK;
 }

@@ -49,9 +49,14 @@
 #ifndef FRISK8_PRE_SPLIT
 #define FRISK8_PRE_SPLIT 1          // shared prefix sums as two arrays - A[] read by one ds_read_b64, W[] by one ds_read_b32 - instead of
 #endif                              // interleaved 12-byte entries (a ds_read2_b32 and a ds_read_b32: half again as many LDS passes)
+#ifndef FRISK8_PLACE
+#define FRISK8_PLACE 1              // orphans are folded into the order-K table where it has room (stage 3): no orphan compares in the scoring loop
+#endif
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
-enum { M8_TSUM = 6,                // misc slots: grand total of the order-8 table (overflow check) ...
+enum { M8_NPLACED = 1,             // misc slots (0, 2, 4, 5: M_UPA, M_UPG, M_NORPH, M_NVALID): orphans folded into the order-K table ...
+       M8_PMASK = 3,               // ... and which entries of the orphan list those are (bit k <-> entry k, which then holds the fake code)
+       M8_TSUM = 6,                // grand total of the order-8 table (overflow check) ...
        M8_SAFE = 7 };              // ... and the code of SOME max-mer of the window (what lanes without one score instead)
 
 // LDS carve-up, all compile-time: the kernels declare it as ONE static array, so every table address is a constant that
@@ -135,7 +140,21 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     constexpr bool CLEAR_ALL = L::t8_bytes / 16 / NT <= uint32_t(ITS);
     // K = 7, 8: thread t sums the table below ITS OWN (K-3)-mers (the 4-mer t / its four 5-mers), so that stage 2 runs inside stage 3: no
     // barrier and no LDS round trip between the table sums and the prefix tables made from them
-    constexpr bool FUSED = (KMAX >= 7 && NT == 256);                 // (K = 7: the 64 counters below the 4-mer t itself)
+    constexpr bool FUSED = (KMAX >= 7 && NT >= 256 && NT % 256 == 0);
+    // Orphans - the (K-1)- and (K-2)-mers that are no prefix of a counted max-mer - need not be compared against every position's
+    // code in the scoring loop: an orphan (K-1)-mer can be ADDED TO THE TABLE as a max-mer that does not occur in the window (a
+    // zero counter among its four children), an orphan (K-2)-mer as one under a (K-1)-mer that does not occur (four zero counters
+    // in a row).  Sums of 4 and of 16 neighbours - c_{K-1}, c_{K-2} - and the table sums of stage 3 then count the orphan like any
+    // max-mer, and the fake counter itself is never read: no position has its code (c_K), and no position sits under a (K-1)-mer
+    // that does not occur.  Stage 3 does this, the thread that owns the orphan's 4-mer (whose sums over that part of the table
+    // follow in program order); where the table has no room the orphan stays on the list and the window takes the scoring loop
+    // with compares.  The same counts either way, so the same bits.  (Debug builds dump every counter: they keep the list.)
+    constexpr bool PLACE = FRISK8_PLACE && FUSED && !DEBUG;
+#ifdef FRISK8_ROLLED
+    constexpr bool ROLLED_K = FRISK8_ROLLED != 0;
+#else
+    constexpr bool ROLLED_K = KMAX < 8 || NT > 256;      // the scoring loop is rolled (two groups per trip) - measured per K, see stage 4
+#endif                 // (K = 7: the 64 counters below the 4-mer t itself)
     __shared__ __attribute__((aligned(16))) unsigned char lds[L::total];
     const int tid0 = threadIdx.x;
     const int kmin0 = P.kmin;
@@ -404,7 +423,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     run = run < rem ? run : rem;
                     run = run < K ? run : K - 1;                         // (a K-mer inside the window would have been a max-mer)
                     const int rs = run < LVL ? run : LVL;
-                    if (rs >= kmin) {
+                    // (PLACE: an orphan reaches the orders <= K-3 through the table sums of stage 3, or - no room - through its owner there)
+                    if (rs >= kmin && !(PLACE && run >= K - 2)) {
                         const uint32_t b = uint32_t(table_offset(kmin, rs)) + (c16 >> (2 * K - 2 * rs));
                         atomicAdd(&small32[b >> 1], 1u << ((b & 1u) * 16));
                     }
@@ -584,26 +604,34 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // has bit 15 set and holds its (K-2)-mer << 2.  o6[k] = the (K-2)-mer of entry k (both kinds count towards c6), o7[k] =
             // the (K-1)-mer of a run-(K-1) entry.  A window without invalid bases has exactly one of each kind (its tail).
             uint32_t o6[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, o7[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            const uint2 first4 = *reinterpret_cast<const uint2*>(orph);            // (one read for the four, not four round trips)
-            static_assert(L::orphans % 8 == 0, "the orphan list is read eight bytes at a time");
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < n_orph) {
-                    const uint32_t e = uni(((k < 2 ? first4.x : first4.y) >> (16 * (k & 1))) & 0xFFFFu);
-                    o6[k] = (e >> 2) & (NK / 16u - 1u);
-                    if (!(e & 0x8000u)) o7[k] = e;
-                }
-            }
             uint32_t o7c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};     // the (K-1)-mers again, compacted: n7 of them
-            int n7 = 0;
+            int n7 = 0, n_list = 0;             // n_list: orphans that stayed on the list (all of them without PLACE)
+            uint32_t rest_mask = 0;             // ... those beyond the first four, as bits over the list's entries
+            static_assert(L::orphans % 8 == 0 && FRISK8_ORPH_CAP <= 32, "the orphan list: eight-byte aligned, one mask bit per entry");
+            // (called behind stage 3's barrier: `placed` = the entries that were folded into the table there)
+            auto load_orphans = [&](uint32_t placed) {
+                uint32_t todo = (n_orph >= 32 ? 0xFFFFFFFFu : ((1u << n_orph) - 1u)) & ~placed;
+                n_list = __popc(todo);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (o7[k] != 0xFFFFFFFFu) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (q == n7) o7c[q] = o7[k];
-                    ++n7;
+                for (int k = 0; k < 4; ++k) {
+                    if (todo) {
+                        const int j = __ffs(int(todo)) - 1;
+                        todo &= todo - 1u;
+                        const uint32_t e = uni(orph[j]);
+                        o6[k] = (e >> 2) & (NK / 16u - 1u);
+                        if (!(e & 0x8000u)) o7[k] = e;
+                    }
                 }
-            }
+                rest_mask = todo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (o7[k] != 0xFFFFFFFFu) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (q == n7) o7c[q] = o7[k];
+                        ++n7;
+                    }
+                }
+            };
             // what a max-mer position reads, all of it addressed by the code alone (so it can be fetched ahead of use):
             // genome-side value, the order-8 counters of its 6-mer / 7-mer / itself, the shared-prefix sums
             struct Fetched { double Ig, A5; uint32_t W5, c8, w7; uint4 w6; };
@@ -611,6 +639,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 Fetched f;
 #ifdef FRISK8_EXP_IGMASK    // (experiment builds, wrong results: the genome-side gather confined to a small footprint)
                 f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + ((c16 & uint32_t(FRISK8_EXP_IGMASK)) << 3));
+#elif defined(FRISK8_EXP_IGNT)  // (experiment builds: the gather as a non-temporal load)
+                f.Ig = __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3)));
+#elif defined(FRISK8_IG_AHEAD)
+                f.Ig = 0.0;                                                                      // (comes from the look-ahead queue)
+                if (ROLLED_K) f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));
 #else
                 f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^K always
 #endif
@@ -672,8 +705,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     c7 += (q7 == o7[k]) ? 1u : 0u;
                     c6 += (q6 == o6[k]) ? 1u : 0u;
                 }
-                for (int k = 4; k < n_orph; ++k) {
-                    const uint32_t e = orph[k];
+                for (uint32_t m = rest_mask; m; m &= m - 1u) {
+                    const uint32_t e = orph[__ffs(int(m)) - 1];
                     c7 += (q7 == e) ? 1u : 0u;
                     c6 += (q6 == ((e >> 2) & (NK / 16u - 1u))) ? 1u : 0u;
                 }
@@ -688,6 +721,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 return x == K ? c8 : (x == K - 1 ? c7 : c6);
             };
             // ---- stage 3: window constants r_x = 4^x / D_x, D_x = (S-(x-1))*2 (L401-409), and the shared prefix tables
+            uint32_t pend0 = 0xFFFFFFFFu, pend1 = 0xFFFFFFFFu;      // PLACE: (list entry << 16 | fake code) of the orphans this thread folded in
             double r_lane = 0.0;
             if (lane <= 8) r_lane = div_exact(double(1u << (2 * lane)), double(int32_t((S - (lane - 1)) * 2)));
             auto r_of = [&](int x) -> double {
@@ -712,8 +746,55 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     // the 3-mers are sums over quads of lanes, the 2-mers over rows of 16, the 1-mer i over wave i - DPP, no
                     // LDS round trip and no barrier between the levels (this was a stage of its own).  The finished counts go
                     // back to the small tables (RIP indices, debug dump) and, from registers, into the prefix sums.
-                    static_assert(NT == 256, "thread t <-> 4-mer t");
+                    static_assert(NT >= 256 && NT % 64 == 0, "thread t <-> 4-mer t: the first four waves (the others sit this stage out)");
+                    if (NT == 256 || tid < 256) {
                     const uint32_t q4 = uint32_t(tid);
+                    // PLACE: the orphans under this thread's 4-mer go into the table before the thread sums that part of it (its
+                    // own LDS operations stay in order).  `extra`: orphans that found no room, per (K-3)-mer of the thread (four
+                    // 16-bit fields at K = 8, one count at K = 7) - what stage 1 would have added to the small table for them.
+                    uint64_t extra = 0;
+                    if constexpr (PLACE) {
+                        pend0 = 0xFFFFFFFFu; pend1 = 0xFFFFFFFFu;
+                        for (int k = 0; k < n_orph; ++k) {              // (uniform; normally two entries: the window's tail)
+                            const uint32_t e = orph[k];
+                            const uint32_t q6 = (e >> 2) & (NK / 16u - 1u);                     // the orphan's (K-2)-mer
+                            if ((q6 >> (2 * (K - 2) - 8)) != q4) continue;
+                            uint32_t slot = 0xFFFFFFFFu;                 // the fake max-mer's code
+                            if constexpr (BITS == 4) {
+                                const uint2 g = *reinterpret_cast<const uint2*>(t8b + q6 * 8u);   // sixteen counters: four (K-1)-mers of four
+                                if (!(e & 0x8000u)) {                    // a (K-1)-mer: a zero counter among its four children
+                                    const uint32_t f = ((e & 2u) ? g.y : g.x) >> ((e & 1u) * 16u) & 0xFFFFu;
+                                    const uint32_t z = ~(f | (f >> 1) | (f >> 2) | (f >> 3)) & 0x1111u;
+                                    if (z) slot = ((e & 0x3FFFu) << 2) | uint32_t((__ffs(int(z)) - 1) >> 2);
+                                } else {                                 // a (K-2)-mer: a (K-1)-mer below it whose four children are all zero
+                                    const uint32_t zz = ((g.x & 0xFFFFu) == 0u ? 1u : 0u) | ((g.x >> 16) == 0u ? 2u : 0u) |
+                                                        ((g.y & 0xFFFFu) == 0u ? 4u : 0u) | ((g.y >> 16) == 0u ? 8u : 0u);
+                                    if (zz) slot = ((q6 << 2) | uint32_t(__ffs(int(zz)) - 1)) << 2;
+                                }
+                            } else {
+                                const uint4 g = *reinterpret_cast<const uint4*>(t8b + q6 * 16u);
+                                if (!(e & 0x8000u)) {
+                                    const uint32_t sub = e & 3u;
+                                    const uint32_t f = sub == 0u ? g.x : (sub == 1u ? g.y : (sub == 2u ? g.z : g.w));
+                                    const uint32_t z = (f - 0x01010101u) & ~f & 0x80808080u;          // (the lowest set bit marks a zero byte)
+                                    if (z) slot = ((e & 0x3FFFu) << 2) | uint32_t((__ffs(int(z)) - 1) >> 3);
+                                } else {
+                                    const uint32_t zz = (g.x == 0u ? 1u : 0u) | (g.y == 0u ? 2u : 0u) | (g.z == 0u ? 4u : 0u) | (g.w == 0u ? 8u : 0u);
+                                    if (zz) slot = ((q6 << 2) | uint32_t(__ffs(int(zz)) - 1)) << 2;
+                                }
+                            }
+                            if (slot != 0xFFFFFFFFu && pend1 == 0xFFFFFFFFu) {
+                                atomicAdd(&t8[slot >> SHW], 1u << ((slot & PERM) * BITS));
+                                // (the entry will name the fake counter, which comes out again after the window - written behind
+                                //  this stage's barrier: the other threads are still reading the list)
+                                if (pend0 == 0xFFFFFFFFu) pend0 = (uint32_t(k) << 16) | slot; else pend1 = (uint32_t(k) << 16) | slot;
+                                atomicOr(&misc[M8_PMASK], 1u << k);
+                                atomicAdd(&misc[M8_NPLACED], 1u);
+                            } else {
+                                extra += K == 8 ? (1ull << (16u * ((q6 >> 2) & 3u))) : 1ull;
+                            }
+                        }
+                    }
                     // c5[m] = the count of the 5-mer 4 q4 + j5[m] (K = 8).  Fused form: the sums of the 64 order-8 counters below each,
                     // read here - thread t owns 128 (256) contiguous table bytes; which 5-mer comes first and which 16 bytes of it
                     // rotate with the lane, so that the eight lanes of a bank group never meet (a b128 read takes eight passes anyway)
@@ -721,7 +802,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     if constexpr (LV == 5) {
                         const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ox[5] + 4 * q4);     // D_5 (fused) or C_5, four u16
                         if constexpr (FUSED) {
-                            const uint64_t d64 = (uint64_t(ch.y) << 32) | ch.x;
+                            const uint64_t d64 = ((uint64_t(ch.y) << 32) | ch.x) + extra;
                             const unsigned char* mine = t8b + q4 * (BITS == 8 ? 256u : 128u);
                             // (all of the thread's table bytes requested before the first is summed: one LDS round trip, not eight)
                             constexpr int NH = BITS == 8 ? 4 : 2;
@@ -781,7 +862,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     //  that is off reads a harmless bin of the first table)
                     const uint32_t d4 = small16[ox[4] + q4], d3 = small16[ox[3] + (q4 >> 2)], d2 = small16[ox[2] + (q4 >> 4)], d1 = small16[q4 >> 6];
                     if (kmin <= 4) {
-                        cx[4] = d4 + below4;
+                        cx[4] = d4 + below4 + (LV == 4 ? uint32_t(extra) : 0u);
                         if constexpr (LV == 4 && FUSED) small16[ox[4] + q4] = uint16_t(cx[4]);
                         if constexpr (LV == 5) {
                             cx[4] += c5[0] + c5[1] + c5[2] + c5[3];
@@ -844,6 +925,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                             }
                         }
                     }
+                    }
                 } else {
 #pragma unroll 2
                     for (uint32_t c = tid; c < NL; c += NT) {
@@ -864,9 +946,27 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             __syncthreads();
             STAMP(5)
-            if constexpr (FUSED) {          // the table's total against the number of max-mer positions: a counter wrapped
-                if (uni(misc[M8_TSUM]) != nvalid_top) { hand_over(); continue; }
+            const uint32_t placed = PLACE ? uni(misc[M8_PMASK]) : 0u;               // entries of the orphan list that went into the table
+            if constexpr (PLACE) {
+                if (pend0 != 0xFFFFFFFFu) orph[pend0 >> 16] = uint16_t(pend0);
+                if (pend1 != 0xFFFFFFFFu) orph[pend1 >> 16] = uint16_t(pend1);
             }
+            // the fakes out again, where the table is not about to be cleared as a whole: subtracted where the table lives on
+            // (a successor slides into it), their words zeroed where every position clears its own word
+            auto remove_fakes = [&]() {
+                if (PLACE && placed && tid < FRISK8_ORPH_CAP && ((placed >> tid) & 1u) && (slide_next || !CLEAR_ALL)) {
+                    const uint32_t slot = orph[tid];
+                    if (slide_next) atomicSub(&t8[slot >> SHW], 1u << ((slot & PERM) * BITS));
+                    else t8[slot >> SHW] = 0u;
+                }
+            };
+            if constexpr (FUSED) {          // the table's total against the number of max-mer positions (and fakes): a counter wrapped
+                if (uni(misc[M8_TSUM]) != nvalid_top + (PLACE ? uni(misc[M8_NPLACED]) : 0u)) {
+                    if (PLACE && placed) __syncthreads();          // (the owners' entries above, before other threads read them)
+                    remove_fakes(); hand_over(); continue;
+                }
+            }
+            load_orphans(placed);
 
             if (DEBUG && P.dbg_counts) {
                 uint32_t* out = P.dbg_counts + row * int64_t(P.nprof);
@@ -974,7 +1074,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #ifdef FRISK8_ROLLED
             constexpr bool ROLLED = FRISK8_ROLLED != 0;
 #else
-            constexpr bool ROLLED = K < 8;
+            constexpr bool ROLLED = K < 8 || NT > 256;
 #endif
             // ALLON: every lane of this wave starts a max-mer at every one of its positions (three waves in four of a window
             // without invalid bases) - no stand-in code to select, no weight to mask
@@ -997,14 +1097,14 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     for (int k = 0; k < GR; ++k) {
                         if (!CHECK || g + k < ITS) {
                             const uint32_t c16 = code4_at(g + k), q6 = c16 >> 4, q7 = c16 >> 2;
-                            constexpr int N6 = ORPH == 2 ? 2 : 4, N7 = ORPH == 2 ? 1 : 4;
+                            constexpr int N6 = ORPH == -1 ? 0 : (ORPH == 2 ? 2 : 4), N7 = ORPH == -1 ? 0 : (ORPH == 2 ? 1 : 4);
 #pragma unroll
                             for (int j = 0; j < N7; ++j) c7[k] += (q7 == o7c[j]) ? 1u : 0u;
 #pragma unroll
                             for (int j = 0; j < N6; ++j) c6[k] += (q6 == o6[j]) ? 1u : 0u;
                             if (ORPH == 0)
-                                for (int j = 4; j < n_orph; ++j) {
-                                    const uint32_t e = orph[j];
+                                for (uint32_t m = rest_mask; m; m &= m - 1u) {
+                                    const uint32_t e = orph[__ffs(int(m)) - 1];
                                     c7[k] += (q7 == e) ? 1u : 0u;
                                     c6[k] += (q6 == ((e >> 2) & (NK / 16u - 1u))) ? 1u : 0u;
                                 }
@@ -1038,6 +1138,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     return;
                 }
                 Fetched buf[2][GR];
+#ifdef FRISK8_IG_AHEAD
+                // the genome-side gathers run FRISK8_IG_AHEAD positions ahead of the arithmetic (the table reads: one group ahead): a
+                // gather that misses L1 takes far longer than a group's arithmetic
+                constexpr int D = FRISK8_IG_AHEAD;
+                double igq[ITS];
+                auto ig_at = [&](int it) -> double { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (code4_at(it) << 3)); };
+#pragma unroll
+                for (int k = 0; k < D && k < ITS; ++k) igq[k] = ig_at(k);
+#endif
 #pragma unroll
                 for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k));
 #pragma unroll
@@ -1045,11 +1154,19 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     const int cur = (g / GR) & 1;
 #pragma unroll
                     for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k));
+#ifdef FRISK8_IG_AHEAD
+#pragma unroll
+                    for (int k = 0; k < GR; ++k) {
+                        if (g + k + D < ITS) igq[g + k + D] = ig_at(g + k + D);
+                        if (g + k < ITS) buf[cur][k].Ig = igq[g + k];
+                    }
+#endif
                     score_group(buf[cur], g, std::true_type{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             constexpr uint32_t ALL_MINE = uint32_t(0xFFFFFFFF00000000ull >> ITS);
+            using orphX = std::integral_constant<int, -1>;                          // no orphan on the list: no compares at all
             using orph2 = std::integral_constant<int, 2>;
             using orph4 = std::integral_constant<int, 4>;
             using orphN = std::integral_constant<int, 0>;
@@ -1059,11 +1176,19 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
                 acode4 = (uint64_t(ah) << 32) | al;
 #endif
-            if (n_orph <= 2 && n7 <= 1) {       // (every window without invalid bases)
-                if (__all(fm4 == ALL_MINE)) score_all(std::true_type{}, orph2{});
-                else score_all(std::false_type{}, orph2{});
-            } else if (n_orph <= 4) score_all(std::false_type{}, orph4{});
-            else score_all(std::false_type{}, orphN{});
+            if constexpr (PLACE) {
+                if (n_list == 0) {              // (every orphan found room in the table: nearly every window)
+                    if (__all(fm4 == ALL_MINE)) score_all(std::true_type{}, orphX{});
+                    else score_all(std::false_type{}, orphX{});
+                } else if (n_list <= 4) score_all(std::false_type{}, orph4{});
+                else score_all(std::false_type{}, orphN{});
+            } else {
+                if (n_list <= 2 && n7 <= 1) {       // (every window without invalid bases)
+                    if (__all(fm4 == ALL_MINE)) score_all(std::true_type{}, orph2{});
+                    else score_all(std::false_type{}, orph2{});
+                } else if (n_list <= 4) score_all(std::false_type{}, orph4{});
+                else score_all(std::false_type{}, orphN{});
+            }
 #ifdef FRISK8_S4_REPEAT
             }
 #endif
@@ -1079,6 +1204,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             STAMP(7)
             // behind the barrier: nobody reads the tables any more.  The whole order-K table in 16-byte stores (8 / 16 per thread at
             // K = 8) is cheaper than every position clearing its own dword (20 tests, extracts and masked 4-byte stores per lane)
+            remove_fakes();
             if (!slide_next) {          // (a successor that slides takes the table as it stands)
                 if constexpr (CLEAR_ALL) clear_t8();
                 else {

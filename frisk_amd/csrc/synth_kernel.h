@@ -2,8 +2,9 @@
 //
 // "Synthetic scaffolds of the named shape" (BASELINE.json): order-3 Markov background, compositional
 // islands drawn from a second, more skewed table, runs of N at two scales, soft-masked runs and - the "repeats"
-// shape - simple repeats at a primate-like density: poly-A / poly-T tails and short-period microsatellites, soft-masked
-// as RepeatMasker / TRF leave them in a released assembly (these are what makes an 8-mer occur 16+ times in 5 kb).  Every
+// shape - simple repeats at a primate-like density: poly-A / poly-T tails and short-period microsatellites (these are what
+// makes an 8-mer occur 16+ times in 5 kb), soft-masked like the rest when the assembly is soft-masked at all (lower_frac > 0:
+// as RepeatMasker / TRF leave a released assembly), uppercase in an unmasked one.  Every
 // property of a base is a pure function of (seed, scaffold index, position), so generation is parallel
 // over 4096-base blocks and frisk_amd/synth.py reproduces the same bytes on the host with numpy.
 #pragma once
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64) void synth_kernel(uint8_t* __restrict__ out, in
             if (in_rep) b = synth_repeat_base(R, p);
             ctx = ((ctx << 2) | b) & 63u;
             uint8_t ch = uint8_t("ATGC"[b]);
-            if (lowr || in_rep) ch |= 0x20;
+            if (lowr || (in_rep && thr_low != 0u)) ch |= 0x20;      // (an assembly is soft-masked - repeats included - or it is not)
             if (nbig || nsmall) ch = 'N';
             out[p] = ch;
         }

@@ -105,6 +105,44 @@ def run_sharded(engine, names, seqs, w, inc, mask_host=False, rip=False, scaffol
     return _gather_rows(dist, group, rank, world, res, seq_global, cand_key, qnames, rip)
 
 
+def _gather_columns(dist, group, rank, world, local):
+    """Per-rank dicts of equally long numpy columns -> list of those dicts on rank 0 (None elsewhere), as TENSORS: one
+    all-gather of the row counts, then every rank sends its columns to rank 0 as one byte buffer (point to point: ranks hold
+    different numbers of rows).  No pickling of Python objects; over RCCL the bytes travel device to device."""
+    import torch
+    if world == 1:
+        return [local]
+    keys = list(local)
+    dtypes = [local[k].dtype for k in keys]
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    n = len(local[keys[0]]) if keys else 0
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=device), group=group)
+    counts = [int(c.item()) for c in counts]
+    width = sum(dt.itemsize for dt in dtypes)
+    if rank != 0:
+        if n:
+            buf = np.concatenate([np.ascontiguousarray(local[k]).view(np.uint8).reshape(-1) for k in keys])
+            dist.send(torch.from_numpy(buf).to(device), dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return None
+    parts = [local]
+    for r in range(1, world):
+        m = counts[r]
+        got = {}
+        if m:
+            t = torch.empty(m * width, dtype=torch.uint8, device=device)
+            dist.recv(t, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+            raw = t.cpu().numpy()
+            o = 0
+            for k, dt in zip(keys, dtypes):
+                got[k] = raw[o:o + m * dt.itemsize].view(dt).copy()
+                o += m * dt.itemsize
+        else:
+            got = {k: np.zeros(0, dt) for k, dt in zip(keys, dtypes)}
+        parts.append(got)
+    return parts
+
+
 def _gather_rows(dist, group, rank, world, res, seq_global, cand_key, qnames, rip):
     """Rows of all ranks on rank 0, in the reference's output order (scaffold order, then candidate order)."""
     keep = res.kept
@@ -113,13 +151,9 @@ def _gather_rows(dist, group, rank, world, res, seq_global, cand_key, qnames, ri
     if rip:
         local.update(pi=res.pi[keep], si=res.si[keep], cri=res.cri[keep])
 
-    if world > 1:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(local, parts, dst=0, group=group)
-        if rank != 0:
-            return None
-    else:
-        parts = [local]
+    parts = _gather_columns(dist, group, rank, world, local)
+    if parts is None:
+        return None
     merged = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
     order = np.lexsort((merged["key"], merged["seq"]))          # scaffold order, then candidate order
     rows = []
@@ -186,11 +220,7 @@ def _gather_table(dist, group, rank, world, res, names, rip):
              "kld": res.kld[keep], "gc": res.gc[keep]}
     if rip:
         local.update(pi=res.pi[keep], si=res.si[keep], cri=res.cri[keep])
-    if world > 1:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(local, parts, dst=0, group=group)
-    else:
-        parts = [local]
+    parts = _gather_columns(dist, group, rank, world, local)
     table, flag = None, [False]
     if rank == 0:
         m = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
@@ -200,8 +230,12 @@ def _gather_table(dist, group, rank, world, res, names, rip):
         int0 = ((m["status"][:n] & _ffi.ROW_NO_MAXMER) != 0).astype(np.uint8)
         table = ScoreTable(names, m["seq"][:n], m["start"][:n], m["stop"][:n], m["kld"][:n], m["gc"][:n],
                            m["pi"][:n] if rip else None, m["si"][:n] if rip else None, m["cri"][:n] if rip else None, int0)
-    if world > 1:
-        dist.broadcast_object_list(flag, src=0, group=group)
+    if world > 1:                               # (one byte, as a tensor)
+        import torch
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        f = torch.tensor([1 if flag[0] else 0], dtype=torch.uint8, device=device)
+        dist.broadcast(f, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        flag = [bool(int(f.item()))]
     return table, bool(flag[0])
 
 

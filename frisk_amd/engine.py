@@ -230,11 +230,20 @@ class Engine:
             return
         n = self.nprof + 4
         if dist.get_backend(group) == "nccl":
-            t = torch.empty(n, dtype=torch.int64, device="cuda:%d" % self.device)
-            self._check(self._lib.frisk_profile_export_device(self._ctx, C.c_void_p(t.data_ptr())))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            torch.cuda.synchronize(t.device)
-            self._check(self._lib.frisk_profile_import_device(self._ctx, C.c_void_p(t.data_ptr())))
+            # in place, on the context's own stream: the library's raw-profile buffer as a torch tensor, the collective issued
+            # under the context's stream (ProcessGroupNCCL chains its own stream to the current one with events, both ways) -
+            # profile_add -> all-reduce -> finalize stay one chain of enqueued work, the host never waits
+            raw, stream = C.c_void_p(), C.c_void_p()
+            self._check(self._lib.frisk_profile_device_view(self._ctx, C.byref(raw), C.byref(stream)))
+
+            class _View:
+                __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(raw.value), False), "version": 2}
+            dev = torch.device("cuda", self.device)
+            t = torch.as_tensor(_View(), device=dev)
+            ext = torch.cuda.ExternalStream(int(stream.value or 0), device=dev)
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            self._allreduce_keep = (t, ext)
         else:
             from .distributed import allreduce_raw_host
             self.profile_set_raw(allreduce_raw_host(self.profile_raw(), group))

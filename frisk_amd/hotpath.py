@@ -11,6 +11,7 @@ SI, CRI]) in the reference's order.  Where the reference would die with ZeroDivi
 (L437: a window max-mer whose prefix has zero weight in the genome) scanGenome raises it too.
 """
 import logging
+import os
 
 import numpy as np
 
@@ -49,6 +50,64 @@ def mapsToProfile(maps, kMin, kMax):
         flat.extend(d[kmerString(c, x)] for c in range(4 ** x))
     r = kMax - kMin
     return (np.asarray(flat, dtype=np.int64), maps[r + 1]["totalLen"], maps[r + 2]["exMax"], maps[r + 3]["nnTotal"])
+
+
+
+SEQ_CACHE_MAGIC = b"FRISK2B1"
+
+
+def seqCachePath(cache_dir, fasta):
+    return os.path.join(cache_dir, os.path.basename(fasta) + ".frisk2bit")
+
+
+def _source_stamp(fasta):
+    st = os.stat(fasta)
+    return [int(st.st_size), int(st.st_mtime_ns)]
+
+
+def writeSeqCache(cache, fasta, names, lens, codes, inv, low):
+    """<magic><u64 header length><json header><codes><inv><low> - written to a temporary name and renamed."""
+    import json
+    head = json.dumps({"source": os.path.abspath(fasta), "stamp": _source_stamp(fasta), "names": names, "lens": [int(x) for x in lens],
+                       "words": [int(codes.size), int(inv.size), int(low.size)]}).encode()
+    tmp = cache + ".tmp%d" % os.getpid()
+    try:
+        with open(tmp, "wb") as fh:
+            fh.write(SEQ_CACHE_MAGIC)
+            fh.write(np.uint64(len(head)).tobytes())
+            fh.write(head)
+            for a in (codes, inv, low):
+                np.ascontiguousarray(a, dtype=np.uint32).tofile(fh)
+        os.replace(tmp, cache)
+    except OSError:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+
+
+def readSeqCache(cache, fasta):
+    """(names, lens, codes, inv, low) - the three arrays memory-mapped - or None when there is no cache for this very file
+    (size and modification time of the FASTA are part of the cache)."""
+    import json
+    try:
+        with open(cache, "rb") as fh:
+            if fh.read(8) != SEQ_CACHE_MAGIC:
+                return None
+            n = int(np.frombuffer(fh.read(8), dtype=np.uint64)[0])
+            head = json.loads(fh.read(n).decode())
+            off = 16 + n
+        if head.get("stamp") != _source_stamp(fasta):
+            return None
+        arrays = []
+        for words in head["words"]:
+            arrays.append(np.memmap(cache, dtype=np.uint32, mode="r", offset=off, shape=(int(words),)))
+            off += 4 * int(words)
+        if os.path.getsize(cache) != off:
+            return None
+        return head["names"], head["lens"], arrays[0], arrays[1], arrays[2]
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def crawlLog(names, sizes, seq_index, kept, w, inc, scaffolds_all, emit=None):
@@ -95,19 +154,49 @@ def _py2_float(x):
 class HotPath:
     """Owns the Engine and the resident batch for one run of the CLI / one test."""
 
-    def __init__(self, kMin, kMax, device=0):
+    def __init__(self, kMin, kMax, device=0, cache_dir=None, use_cache=True):
         self.engine = Engine(kMin, kMax, device)
         self.kMin, self.kMax = kMin, kMax
         self._resident = None       # path of the FASTA whose scaffolds are on the device
         self.names = []
+        # packed-sequence cache (beside the reference's pickle caches in --tempDir): <fasta basename>.frisk2bit holds the 2-bit
+        # codes and the two bitmaps exactly as they lie in HBM, so a later run on the same file neither parses (nor inflates) it
+        # nor packs it, and PCIe carries 0.5 B per base.  use_cache=False (--recalc given): ignore and rewrite it.
+        self.cache_dir, self.use_cache = cache_dir, use_cache
+        self.loaded_from_cache = False
+        self._writer = None
 
     def close(self):
+        self._join_writer()
         self.engine.close()
 
+    def _join_writer(self):
+        if self._writer is not None:
+            self._writer.join()
+            self._writer = None
+
     def _load(self, path):
-        if self._resident != path:
-            self.names = self.engine.load_fasta(path)       # native reader (iterFasta semantics, L139-164)
-            self._resident = path
+        if self._resident == path:
+            return
+        cache = seqCachePath(self.cache_dir, path) if self.cache_dir else None
+        self.loaded_from_cache = False
+        if cache and self.use_cache:
+            got = readSeqCache(cache, path)
+            if got is not None:
+                names, lens, codes, inv, low = got
+                self.engine.stage_packed(codes, inv, low, lens)
+                self.engine.commit(names)
+                self.names, self._resident, self.loaded_from_cache = names, path, True
+                return
+        self.names = self.engine.load_fasta(path)           # native reader (iterFasta semantics, L139-164)
+        self._resident = path
+        if cache:
+            self._join_writer()
+            codes, inv, low = self.engine.export_packed()
+            import threading                                # (the file is written while the profile and the scan run)
+            self._writer = threading.Thread(target=writeSeqCache, args=(cache, path, list(self.names), list(self.engine.seq_lens),
+                                                                        codes, inv, low), daemon=False)
+            self._writer.start()
 
     # phase A -----------------------------------------------------------------------------------
     def genomeProfile(self, args, allreduce=False):

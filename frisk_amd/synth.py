@@ -10,8 +10,11 @@ bytes: every property of a base is a pure function of (seed, scaffold index, pos
                 probability 0.2*n_frac
   * soft mask : units of 512 bases are lower-cased with probability lower_frac
   * repeats   : units of 512 bases hold one simple repeat (poly-A x3 / poly-T x2 / (CA)n / (TG)n / (AAAT)n, 12..31 bases,
-                one in four up to 91) with probability repeats_per_kb * 0.512; soft-masked.  REPEATS_HG38 below is the
-                "realistic" shape of the bench: what a released primate assembly looks like to the counter widths
+                one in four up to 91) with probability repeats_per_kb * 0.512; soft-masked when lower_frac > 0 (a soft-masked
+                assembly), uppercase otherwise.  REPEATS_SOFT / REPEATS_UNMASKED below are the "realistic" shapes of the
+                bench: a primate assembly as UCSC distributes it (soft-masked: the reference's 30 % filter - which counts
+                lowercase as unresolved, L106-118 - then drops most windows) and as an unmasked download (every window
+                scored, and poly-A tails / microsatellites overflow 4-bit counters in almost half of them)
 """
 import numpy as np
 
@@ -21,8 +24,9 @@ NBIG_BLOCKS = 8
 NSMALL = 1024
 LOWER = 512
 REP = 512
-# the bench's second shape: one simple repeat per ~3 kb (Alu poly-A tails + microsatellites), 45 % soft-masked, 7 % N
-REPEATS_HG38 = dict(island_frac=0.02, n_frac=0.07, lower_frac=0.45, repeats_per_kb=0.35)
+# the bench's realistic shapes: one simple repeat per ~3 kb (Alu poly-A tails + microsatellites), 7 % N
+REPEATS_SOFT = dict(island_frac=0.02, n_frac=0.07, lower_frac=0.45, repeats_per_kb=0.35)
+REPEATS_UNMASKED = dict(island_frac=0.02, n_frac=0.07, lower_frac=0.0, repeats_per_kb=0.35)
 GOLDEN = np.uint64(0x9E3779B97F4A7C15)
 _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
@@ -118,7 +122,9 @@ def scaffold(length, seed, scaf_index, island_frac=0.02, n_frac=0.0, lower_frac=
     seq = out.reshape(-1)[:length].copy()
     pos = np.arange(length, dtype=np.uint64)
     low = _unit_hash(seed, scaf_index, pos // np.uint64(LOWER), 4) < np.uint32(frac_to_u32(lower_frac))
-    seq[low | in_rep.reshape(-1)[:length]] |= 0x20
+    if frac_to_u32(lower_frac) != 0:            # an assembly is soft-masked - repeats included - or it is not
+        low = low | in_rep.reshape(-1)[:length]
+    seq[low] |= 0x20
     nbig = _unit_hash(seed, scaf_index, pos // np.uint64(BLOCK * NBIG_BLOCKS), 2) < np.uint32(frac_to_u32(n_frac * 0.8))
     nsmall = _unit_hash(seed, scaf_index, pos // np.uint64(NSMALL), 3) < np.uint32(frac_to_u32(n_frac * 0.2))
     seq[nbig | nsmall] = ord("N")

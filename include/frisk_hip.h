@@ -135,6 +135,11 @@ int64_t frisk_seq_padded_len(const frisk_ctx* ctx);
 int64_t frisk_profile_raw_len(const frisk_ctx* ctx);
 int frisk_profile_export_device(frisk_ctx* ctx, void* dst_device_int64);
 int frisk_profile_import_device(frisk_ctx* ctx, const void* src_device_int64);
+/* The same without copies and without the host: *raw = the raw profile's own device buffer (int64[frisk_profile_raw_len()]),
+ * *stream = the context's HIP stream (a hipStream_t).  A collective library sums the buffer IN PLACE ON THAT STREAM - RCCL's
+ * all-reduce over xGMI, issued under torch.cuda.ExternalStream(*stream) - so that profile_add -> all-reduce -> finalize is
+ * one chain of enqueued work.  The call marks the profile as changed (as frisk_profile_import_device does). */
+int frisk_profile_device_view(frisk_ctx* ctx, void** raw, void** stream);
 int frisk_profile_export_host(frisk_ctx* ctx, int64_t* dst_host);
 int frisk_profile_import_host(frisk_ctx* ctx, const int64_t* src_host);
 int frisk_profile_finalize(frisk_ctx* ctx);

@@ -96,3 +96,29 @@ def test_large_record_buffer_paths(tmp_path):
     a, b = _native(path), _native(gz)
     assert a[0] == 0 and a[1] == 2 and a[2] == 70_000_008
     assert a == b
+
+
+def test_packed_sequence_cache_file_roundtrip(tmp_path):
+    """The .frisk2bit file (frisk_amd/hotpath.py): what was written comes back memory-mapped, and only for the very FASTA it
+    was made from (size and modification time are part of the cache)."""
+    import numpy as np
+    from frisk_amd.hotpath import readSeqCache, seqCachePath, writeSeqCache
+    fa = tmp_path / "g.fa"
+    fa.write_text(">a\nACGTNNacgt\n>b\nAC\n")
+    cache = seqCachePath(str(tmp_path), str(fa))
+    assert cache.endswith("g.fa.frisk2bit")
+    rng = np.random.default_rng(1)
+    codes, inv, low = (rng.integers(0, 2 ** 32, size=n, dtype=np.uint32) for n in (8, 4, 4))
+    writeSeqCache(cache, str(fa), ["a", "b"], [10, 2], codes, inv, low)
+    names, lens, c2, i2, l2 = readSeqCache(cache, str(fa))
+    assert names == ["a", "b"] and lens == [10, 2]
+    assert np.array_equal(c2, codes) and np.array_equal(i2, inv) and np.array_equal(l2, low)
+    fa.write_text(">a\nACGTNNacgtA\n>b\nAC\n")               # another file now
+    assert readSeqCache(cache, str(fa)) is None
+    assert readSeqCache(str(tmp_path / "none.frisk2bit"), str(fa)) is None
+    with open(cache, "r+b") as fh:                            # truncated file
+        fh.truncate(40)
+    writeSeqCache(cache, str(fa), ["a", "b"], [11, 2], codes, inv, low)
+    with open(cache, "r+b") as fh:
+        fh.truncate(os.path.getsize(cache) - 4)
+    assert readSeqCache(cache, str(fa)) is None

@@ -178,3 +178,33 @@ def test_cli_logs_the_reference_progress_lines(tmp_path, caplog, case):
     got = [r.getMessage() for r in caplog.records if r.name == "frisk_amd"]
     first = got.index(want[0])
     assert got[first:first + len(want)] == want
+
+
+def test_cli_packed_sequence_cache(tmp_path, capsys):
+    """<fasta>.frisk2bit beside the pickle caches: written by the first run, used by the second (no parse, no pack: the table is
+    the same text), ignored and rewritten with --recalc, and not trusted once the FASTA has changed."""
+    import shutil
+    from frisk_amd.cli import main
+    from frisk_amd.hotpath import readSeqCache
+    c = Case("k8_w2000")
+    fa = tmp_path / "genome.fa"
+    shutil.copy(c.host, fa)
+    T = tmp_path / "T"
+    argv = ["-H", str(fa), "-k", "8", "-w", "2000", "-i", "500", "-t", str(T), "--recalcWin", "--exitAfter", "WindowKLD"]
+    assert main(argv) == 0
+    first = open(T / "raw_window_scores.bed").read()
+    cache = T / "genome.fa.frisk2bit"
+    assert cache.is_file() and readSeqCache(str(cache), str(fa)) is not None
+    assert len(first.splitlines()) == 1 + len(c.rows)
+    t0 = os.path.getmtime(cache)
+    assert main(argv) == 0                                          # the profile pickle and the sequence cache are both reused
+    assert open(T / "raw_window_scores.bed").read() == first and os.path.getmtime(cache) == t0
+    assert main(argv + ["--recalc"]) == 0                           # --recalc: recompute - and rewrite the cache
+    assert open(T / "raw_window_scores.bed").read() == first and os.path.getmtime(cache) >= t0
+    # the FASTA changes (one more record): the cache is for another file now
+    with open(fa, "a") as fh:
+        fh.write(">extra\n" + "ACGT" * 700 + "\n")
+    assert readSeqCache(str(cache), str(fa)) is None
+    assert main(argv + ["--recalc"]) == 0
+    assert len(open(T / "raw_window_scores.bed").read().splitlines()) > len(first.splitlines())
+    capsys.readouterr()

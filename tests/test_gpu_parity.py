@@ -26,9 +26,11 @@ def synth_seqs(lens, seed, **kw):
     return [synth.scaffold(n, seed, i, **kw) for i, n in enumerate(lens)]
 
 
-def test_device_generator_equals_host_generator():
+@pytest.mark.parametrize("kw", [dict(island_frac=0.4, n_frac=0.25, lower_frac=0.3),
+                                dict(island_frac=0.1, n_frac=0.05, lower_frac=0.3, repeats_per_kb=1.2),      # soft-masked, with repeats
+                                dict(island_frac=0.1, n_frac=0.05, lower_frac=0.0, repeats_per_kb=1.9)])     # unmasked, with repeats
+def test_device_generator_equals_host_generator(kw):
     lens = [10000, 4096, 4097, 1, 33000, 70001]
-    kw = dict(island_frac=0.4, n_frac=0.25, lower_frac=0.3)
     with make_engine(1, 4) as e:
         e.synth(lens, seed=99, **kw)
         host = synth_seqs(lens, 99, **kw)
@@ -357,7 +359,7 @@ def test_many_small_scaffolds():
             assert worst <= KLD_TOL
 
 
-@pytest.mark.parametrize("shape", ["C1", "C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("shape", ["C1", "C2", "C3", "C4", "C5", "C5/8 unmasked repeats", "C5/8 soft-masked repeats"])
 def test_full_size_rows_against_c_oracle(shape):
     """BASELINE configs at full size, row by row against the compiled CPU oracle (oracle/frisk_oracle_c.c, pinned to the
     reference's golden vectors by tests/test_oracle_c.py): profile bit-exact, kept set / coordinates / GC bit-exact,
@@ -372,13 +374,24 @@ def test_full_size_rows_against_c_oracle(shape):
         lens, kmin, kmax, w, inc, nfrac, slices = synth.C3_LENS, 1, 8, 5000, 1000, 0.001, [(0, -1)]
     elif shape == "C4":
         lens, kmin, kmax, w, inc, nfrac, slices = synth.C4_LENS, 1, 8, 2000, 500, 0.07, [(0, -1)]
-    else:
+    elif shape == "C5":
         lens = [n for r in range(8) for n in synth.c5_shard_lens(8, r)]
         kmin, kmax, w, inc, nfrac = 1, 8, 5000, 1000, 0.07
         slices = [(0, 20000), (1_600_000, 1_620_000), (3_260_000, 3_280_000)]
+    else:
+        # the bench's "realistic" shapes on the bench's shard (410 Mb): simple repeats at a primate-like density - poly-A / T tails
+        # and microsatellites that wrap 4-bit counters in almost half the windows of the unmasked form (the adaptive width then
+        # takes 8-bit counters for the bulk), and a soft-masked form in which the reference's 30 % filter drops most windows
+        lens = synth.c5_shard_lens(8, 0)
+        kmin, kmax, w, inc, nfrac = 1, 8, 5000, 1000, 0.07
+        slices = [(0, 30000), (200_000, 230_000), (380_000, 410_000)]
     with make_engine(kmin, kmax) as e:
-        seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5}[shape]
+        seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5}.get(shape, 0xC5)
         kw = dict(island_frac=0.02, n_frac=nfrac, lower_frac=0.01)
+        if shape == "C5/8 unmasked repeats":
+            kw = dict(synth.REPEATS_UNMASKED)
+        elif shape == "C5/8 soft-masked repeats":
+            kw = dict(synth.REPEATS_SOFT)
         if shape in ("C1", "C2", "C3"):
             # the oracle's input is generated on the HOST (frisk_amd/synth.py) and uploaded as ASCII: the GPU's pack, its
             # counters and its scores are all on the checked path, nothing the oracle sees has passed through the device
@@ -412,6 +425,8 @@ def test_full_size_rows_against_c_oracle(shape):
             assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
             checked += len(k)
         assert checked > (5000 if shape != "C1" else 40)
+        if shape == "C5/8 unmasked repeats":        # the path real assemblies take: 8-bit counters for the bulk of the scan
+            assert e.scan_stat()[0] == 8
 
 
 @pytest.mark.parametrize("want_rip", [False, True])

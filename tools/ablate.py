@@ -17,13 +17,13 @@ sys.path.insert(0, %r)
 from frisk_amd import Engine, synth
 lens = [int(x*%f) for x in synth.c5_shard_lens(8, 0)]
 e = Engine(1, %d)
-e.synth(lens, seed=0xC5, island_frac=0.02, n_frac=0.07)
+e.synth(lens, seed=0xC5, island_frac=0.02, n_frac=0.07, lower_frac=%f, repeats_per_kb=%f)
 e.profile_reset(); e.profile_add(); e.profile_finalize()
 ts = []
 for _ in range(4):
     r = e.scan(5000, 1000, pinned=True); ts.append(e.kernel_ms(0))
 e.profile_reset(); e.profile_add(); tp = e.kernel_ms(1)
-print(json.dumps({"scan_ms": min(ts), "profile_ms": tp, "cands": r.n_candidates, "kld_sum": float(r.kld[r.kept].sum())}))
+print(json.dumps({"scan_ms": min(ts), "profile_ms": tp, "cands": r.n_candidates, "kld_sum": float(r.kld[r.kept].sum()), "stat": e.scan_stat()}))
 '''
 
 
@@ -37,7 +37,7 @@ def main():
                         "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", lib,
                         os.path.join(CSRC, "frisk_abi.hip"), "-lz"] + defs, check=True)
         env = dict(os.environ, FRISK_HIP_LIB=lib)
-        out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, scale, CHILD_K)], env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, scale, CHILD_K, float(os.environ.get("ABLATE_LOWER", "0")), float(os.environ.get("ABLATE_REPEATS", "0")))], env=env, capture_output=True, text=True)
         print(spec, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:], flush=True)
         for line in out.stderr.splitlines():
             if line.startswith("[stamps]"):

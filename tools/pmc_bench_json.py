@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/r2_pmc_bench.json from one tools/profile_round.sh directory: per-launch HBM traffic of the dominant scan kernel
+"""profiles/r<N>_pmc_bench.json from one tools/profile_round.sh directory: per-launch HBM traffic of the dominant scan kernel
 (2 x FETCH_SIZE + WRITE_SIZE: gfx950 reports half of the fetched bytes of wide streaming reads, MI355X_MICROARCH.md, HBM) and
 the `binding` block bench.py prints - what actually bounds the kernel, from the SQ counters and the kernel trace."""
 import csv
 import json
 import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # noqa: E402   (the hash bench.py checks before it quotes this file)
 
 root = sys.argv[1]
 pm = json.load(open(os.path.join(root, "pmc_summary.json")))
@@ -54,6 +57,7 @@ pos_per_win = 4993.0
 fp64_lane_ops = n_win * pos_per_win * f64_per_pos / (dur_ns[0] * 1e-9)      # one lane scores one position
 out = {
     "kernel": scan.split("(")[0].strip(),
+    "csrc_sha256": csrc_hash(),            # frisk_amd/csrc/* + include/*.h these counters were taken from
     "workload_bases_per_gpu": cfg["bases_per_gpu"], "candidate_windows_per_gpu": n_win,
     "scan_ms_per_step_rocprofv3": dur_ns[0] * 1e-6, "scan_launches": names,
     "FETCH_SIZE_KB_per_launch": c.get("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": c.get("WRITE_SIZE"),
