@@ -235,7 +235,7 @@ def shape_block(eng, lens, kw, step, fence, steps, label):
             "max_kld": float(np.nanmax(res.kld[res.kept])) if rows else None}
 
 
-def strong_block(eng, dist, torch, rank, world, local_seed, fence, steps):
+def strong_block(eng, dist, torch, rank, world, red_dev, fence, steps):
     """The whole C5 shape as ONE job over the N ranks: every rank holds the packed assembly (4.9 GB of 288), counts the k-mers
     that start in its N-th of the positions, the raw profiles are summed by the one all-reduce, and every rank scores its N-th
     of the candidate windows (contiguous ranges in output order; rows stay on the rank, as in the weak steps).  N = 1 is the
@@ -262,7 +262,7 @@ def strong_block(eng, dist, torch, rank, world, local_seed, fence, steps):
     dt, res, scan_ms = timed_steps(step, fence, 2, steps)
     rows = int(res.kept.sum())
     if dist is not None:
-        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -330,11 +330,20 @@ def main(argv=None):
         if rank == 0:
             print(json.dumps({"dry_run": True, "world": world, "ranks_seen": seen}), flush=True)
         return
+    # FRISK_BENCH_REHEARSAL=1: the N-rank code path on ONE GPU (every rank on device 0, gloo instead of RCCL - RCCL refuses two
+    # ranks on one device): a functional rehearsal of what the driver runs on N GPUs, its numbers mean nothing
+    rehearsal = os.environ.get("FRISK_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    red_dev = "cpu" if rehearsal else "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from frisk_amd import Engine, synth
     lens = [max(1, int(x * opts.shard_scale)) for x in synth.c5_shard_lens(8, rank % 8)]
@@ -371,7 +380,7 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     rows = int(res.kept.sum())                              # (every step emits the same rows: counted once, outside the timed region)
     if dist is not None:
-        t = torch.tensor([elapsed, float(rows), float(total_bases), float(n_cand)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(rows), float(total_bases), float(n_cand)], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -389,7 +398,7 @@ def main(argv=None):
         cold = {"cold_first_step_ms": cold_ms, "cold_first_scan_kernel_ms": cold_scan_ms,
                 "note": "first step on a batch that has just become resident: includes the 1/16 sample of the adaptive counter "
                         "width and its host synchronisation; the steps behind `value` reuse the sample's verdict"}
-        strong = strong_block(eng, dist, torch, rank, world, 0xC5, fence, few)
+        strong = strong_block(eng, dist, torch, rank, world, red_dev, fence, few)
         if world == 1:
             for label, kw in (("unmasked assembly with simple repeats", synth.REPEATS_UNMASKED),
                               ("soft-masked assembly with simple repeats", synth.REPEATS_SOFT)):
@@ -452,6 +461,7 @@ def main(argv=None):
                          "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
                                  "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding`"},
             "binding": binding,
+            **({"rehearsal_on_one_gpu": True} if rehearsal else {}),
             "cold": cold,
             "strong": strong,
             "realistic": realistic,

@@ -107,10 +107,11 @@ inline bool for_lines(const char* base, size_t size, size_t b, size_t e, OnSeq&&
     return true;
 }
 
-inline bool parse_plain(const char* base, size_t size, Records& out, std::string& err) {
+inline bool parse_plain(const char* base, size_t size, Records& out, std::string& err, int max_threads = 32) {
     unsigned hw = std::thread::hardware_concurrency();
     int T = int(hw ? hw : 1);
     if (T > 32) T = 32;
+    if (T > max_threads) T = max_threads < 1 ? 1 : max_threads;      // (N ranks of one node parse the same file at the same time)
     if (size < (size_t(1) << 24)) T = 1;
     std::vector<size_t> cut(size_t(T) + 1, size);
     cut[0] = 0;
@@ -222,7 +223,7 @@ inline bool parse_gz(const char* path, Records& out, std::string& err) {
     return true;
 }
 
-inline bool parse(const char* path, Records& out, std::string& err) {
+inline bool parse(const char* path, Records& out, std::string& err, int max_threads = 32) {
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) { err = std::string("cannot open FASTA file: ") + path; return false; }
     struct stat sb;
@@ -236,7 +237,7 @@ inline bool parse(const char* path, Records& out, std::string& err) {
         if (m == MAP_FAILED) { ::close(fd); ok = parse_gz(path, out, err); }
         else {
             ::madvise(m, size_t(sb.st_size), MADV_SEQUENTIAL);
-            ok = parse_plain(static_cast<const char*>(m), size_t(sb.st_size), out, err);
+            ok = parse_plain(static_cast<const char*>(m), size_t(sb.st_size), out, err, max_threads);
             ::munmap(m, size_t(sb.st_size));
             ::close(fd);
         }

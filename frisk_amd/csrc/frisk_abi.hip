@@ -114,6 +114,7 @@ struct frisk_ctx {
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
     DevBuf<double> d_ig, d_logtab, d_logtab64, d_logtab32, d_rctab;
     DevBuf<int64_t> d_ovf_list, d_ovf_list2;   // windows handed from 4-bit to 8-bit counters, and from there to the 16-bit form
+    DevBuf<double> d_ig_ring;                  // scan8_kernel: per-workgroup ring of genome-side values by position (80 KB each at 20 positions per lane)
     DevBuf<unsigned int> d_ovf_count;          // per row segment 32 counters: [0], [1] the lists' lengths, [8..15] the bulk launch's chunk queues, [16] the 8-bit launch's
     int64_t scan_stat[4] = {0, 0, 0, 0};       // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16, row segments
     DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
@@ -664,7 +665,9 @@ int frisk_fasta_load_shard(frisk_ctx* c, const char* path, int32_t w, int32_t in
     if (world < 1 || rank < 0 || rank >= world) return fail(c, FRISK_E_ARG, "rank outside [0, world)");
     frisk_fasta::Records rec;
     std::string err;
-    if (!frisk_fasta::parse(path, rec, err)) return fail(c, FRISK_E_ARG, err);
+    // (the ranks of a job parse the same file at the same time, normally on one node: each takes its share of the host's threads)
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (!frisk_fasta::parse(path, rec, err, int(std::max(1u, (hw ? hw : 1u) / unsigned(world))))) return fail(c, FRISK_E_ARG, err);
     const std::vector<int64_t>& lens = rec.lens;
     const std::vector<std::string>& names = rec.names;
     const frisk_fasta::ByteVec& stage = rec.stage;
@@ -679,15 +682,16 @@ int frisk_fasta_load_shard(frisk_ctx* c, const char* path, int32_t w, int32_t in
     int rc = layout_batch(c, tlen.data(), int32_t(tiles.size()));
     if (rc) return rc;
     frisk_ctx::Batch& B = c->b();
-    // the rank's tiles, gathered into one upload buffer in the batch layout
-    std::vector<uint8_t> up(size_t(B.padded_len), uint8_t(FRISK_PAD_BYTE));
-    for (size_t t = 0; t < tiles.size(); ++t)
-        if (tlen[t] > 0)
-            std::memcpy(up.data() + B.seq_off[t], stage.data() + rec_off[size_t(tiles[t].scaf)] + tiles[t].base0, size_t(tlen[t]));
+    // the rank's tiles straight from the parser's buffer into the batch layout on the device (no second host copy of them):
+    // PAD everywhere first, then one upload per tile
     HIPC(c, B.d_ascii.reserve(size_t(B.padded_len)));
-    rc = h2d(c, B.d_ascii.p, up.data(), up.size(), c->stream);
-    if (rc) return rc;
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemsetAsync(B.d_ascii.p, FRISK_PAD_BYTE, size_t(B.padded_len), c->stream));
+    for (size_t t = 0; t < tiles.size(); ++t) {
+        if (tlen[t] <= 0) continue;
+        rc = h2d(c, B.d_ascii.p + B.seq_off[t], stage.data() + rec_off[size_t(tiles[t].scaf)] + tiles[t].base0, size_t(tlen[t]), c->stream);
+        if (rc) return rc;
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));          // (the parser's buffer goes away with this call)
     rc = alloc_packed(c);
     if (rc) return rc;
     rc = run_pack(c);
@@ -1049,9 +1053,31 @@ int frisk_scan_plan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_
     return FRISK_OK;
 }
 
+static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1, int64_t cap,
+                     int32_t* seq_index, int64_t* start, int64_t* stop, uint32_t* status, double* kld, double* gc,
+                     double* pi, double* si, double* cri, uint32_t* dbg_counts, int64_t* dbg_meta);
+
 int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1, int64_t cap,
                int32_t* seq_index, int64_t* start, int64_t* stop, uint32_t* status, double* kld, double* gc,
                double* pi, double* si, double* cri, uint32_t* dbg_counts, int64_t* dbg_meta) {
+    const int rc = scan_impl(c, w, inc, flags, c0, c1, cap, seq_index, start, stop, status, kld, gc, pi, si, cri, dbg_counts, dbg_meta);
+    if (rc != FRISK_OK && c) {
+        // a failure after work was queued: copies may still target the caller's row buffers (and locals of the call), kernels of
+        // the tail segment may still run - nothing of this call is in flight once it has returned
+        const std::string msg = c->err;
+        if (hipSetDevice(c->device) == hipSuccess) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->tail_stream);
+            (void)hipGetLastError();
+        }
+        c->err = msg;
+    }
+    return rc;
+}
+
+static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1, int64_t cap,
+                     int32_t* seq_index, int64_t* start, int64_t* stop, uint32_t* status, double* kld, double* gc,
+                     double* pi, double* si, double* cri, uint32_t* dbg_counts, int64_t* dbg_meta) {
     if (!c) return FRISK_E_ARG;
     if (!c->profile_final) return fail(c, FRISK_E_STATE, "frisk_scan: genome profile not finalised");
     int64_t ncand_all = 0;
@@ -1105,7 +1131,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
     }
     P.stamps = nullptr;
     P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
-    P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr; P.queue_n = 1; P.slide_pp = 0;
+    P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr; P.queue_n = 1; P.slide_pp = 0; P.ig_ring = nullptr;
     c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0; c->scan_stat[3] = 1;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
@@ -1206,6 +1232,12 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         // counters first, and the share of it that had to be handed on decides the width for the other fifteen.  All three
         // forms give the same bits for a window (same arithmetic; 16-bit only ever sees the windows that wrap 8 bits), so
         // results do not depend on the choice, on the grid, or on the candidate range.
+        // the ring through which genome-side values travel from window to window (scan8_kernel.h): one slice per workgroup of the
+        // largest grid these kernels are launched with (four 256-thread workgroups per CU at K = 6, 7), 20 rows of 512 columns
+        // ... behind a copy of the genome table itself (one base address for both, scan8_kernel.h)
+        HIPC(c, c->d_ig_ring.reserve(nk + size_t(c->num_cu) * 4 * 20 * FRISK8_RING_COLS));
+        HIPC(c, hipMemcpyAsync(c->d_ig_ring.p, c->d_ig.p, nk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        P.ig_ring = c->d_ig_ring.p;
         HIPC(c, c->d_ovf_list.reserve(N));
         HIPC(c, c->d_ovf_list2.reserve(N));
         HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 64 * sizeof(unsigned int), c->stream));
@@ -1225,6 +1257,7 @@ int frisk_scan(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64_t c0,
         frisk_ctx::Batch& RB = c->b();
         const bool hinted = RB.width_hint != 0 && RB.hint_w == w && RB.hint_inc == inc;
         if (narrow7) { /* 8-bit bulk, no sample */ }
+        else if ((flags & FRISK_SCAN_BITS4) && narrow8) bulk = 4;
         else if (width == 0 && !debug && hinted) bulk = RB.width_hint;      // same batch, same geometry: the earlier sample still holds
         else if (width == 0 && !debug && nchunks >= 64 * P.sel_mod) {
             ScanParams S = P;                   // the sample

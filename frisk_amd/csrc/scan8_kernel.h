@@ -52,6 +52,10 @@
 #ifndef FRISK8_PLACE
 #define FRISK8_PLACE 1              // orphans are folded into the order-K table where it has room (stage 3): no orphan compares in the scoring loop
 #endif
+#ifndef FRISK8_RING
+#define FRISK8_RING 1               // genome-side values travel from window to window through a per-workgroup ring in global memory (below)
+#endif
+#define FRISK8_RING_COLS 512        // ring geometry: ITS rows x 512 columns of doubles per workgroup (position p <-> row p % ITS, column p / ITS % 512)
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
 enum { M8_NPLACED = 1,             // misc slots (0, 2, 4, 5: M_UPA, M_UPG, M_NORPH, M_NVALID): orphans folded into the order-K table ...
@@ -224,7 +228,28 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     // Everything else of a window - composition, short words, orphans, stages 3 and 4 - is computed as before, by the same
     // lanes in the same order: rows do not depend on whether a window was slid into or counted afresh.
     const int slide_pp = P.in_list == nullptr ? P.slide_pp : 0;
+    // THE GENOME-SIDE GATHER.  Every scored position needs Ig[its max-mer] - 8 bytes at a random place of a 512 KB table, which
+    // costs a whole 128-byte line from L2 each: 5 000 lines per window, 247 GB per scan of the bench shard, which at the L2's
+    // ~34 TB/s IS the scan's 7.4 ms (round 3's ablations: with the gather confined to L1 the same kernel took 15 % less, and no
+    // diet of instructions or LDS reads showed while the gather stood).  But a position's max-mer - hence its Ig - is the same
+    // in every window that covers it, and consecutive windows share w - inc of w positions.  So the value is gathered ONCE, by
+    // the scoring loop of the first window of the chunk that scores the position - a window counted afresh: every lane; a window
+    // slid into: the lanes that hold its entering range - and parked in a ring in global memory that belongs to this workgroup,
+    // indexed by the position in the scaffold: row = p % ITS, column = p / ITS % 512.  The other lanes read ring[p] instead of
+    // Ig[code]: for a fixed step `it` of the scoring loop the lanes' positions are ITS apart, i.e. the same row and consecutive
+    // columns - 512 contiguous bytes per wave instruction instead of 64 lines.  Every lane writes the value it used back (a lane
+    // that read the ring rewrites what it read; a position that starts no max-mer parks a 1.0 - its stand-in has weight 0), so the
+    // loop has no branch on who is who: the load's offset is a select between two, the store is unconditional.  L2 -> L1 traffic
+    // per window: about inc gathers + w coalesced doubles (170 KB) instead of w gathers (640 KB).  Same values, same lanes, same
+    // order of summation: same bits.  (The ring lives in L2 / Infinity Cache: 80 KB per workgroup.)
+    constexpr bool RING = FRISK8_RING != 0;
+    // (one buffer: a copy of the genome table first, the workgroups' slices behind it - so that "from the table" and "from the
+    //  ring" are two 32-bit offsets from one base, and the scoring loop's load is one instruction either way)
+    char* const ring = RING ? reinterpret_cast<char*>(P.ig_ring) : nullptr;
+    const uint32_t slice_off = RING ? uint32_t((size_t(NK) + size_t(blockIdx.x) * size_t(ITS) * FRISK8_RING_COLS) * 8) : 0u;
     bool slide_next = false;            // the table is left standing for the next window (which slides); false: it is cleared
+    bool ring_next = false;             // ... and so is the ring: the window before this one went through the scoring loop (a window
+                                        // that the N filter drops, or that is handed on, parks nothing - its successor gathers afresh)
 #ifdef FRISK_STAMPS
     int stamp_win = -1;         // (diagnostic builds: STAMP of scan_kernel.h - wave 0 of the first workgroups, s_memtime per stage)
 #endif
@@ -324,7 +349,24 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const int64_t row = cand - P.c0;
             // this window slides into the table its predecessor left; its successor - the next candidate of this chunk, in the
             // same scaffold, a full window like this one (no jumpback, L230-232) - will slide into this one's
+            // where the window's first base sits in the ring: row rb_r, column rb_q (uniform)
+            const uint32_t ring_base = RING ? uint32_t(uint64_t(st) % uint64_t(ITS * FRISK8_RING_COLS)) : 0u;
+            const uint32_t rb_q = ring_base / uint32_t(ITS), rb_r = ring_base - rb_q * uint32_t(ITS);
+            // byte offset (from the buffer's base) of the ring's place for this lane's it-th position
+            auto ring_mine = [&](int it) __attribute__((always_inline)) -> uint32_t {
+                const uint32_t rr = rb_r + uint32_t(it);                         // (uniform: the row, and whether it wraps into the next column)
+                const uint32_t cy = rr >= uint32_t(ITS) ? 1u : 0u;
+                return slice_off + ((((rr - cy * uint32_t(ITS)) * FRISK8_RING_COLS) + ((rb_q + cy + uint32_t(tid)) & (FRISK8_RING_COLS - 1u))) << 3);
+            };
             const bool sliding = slide_next;
+            // this lane gathers its positions' genome-side values from the table (and parks them in the ring): every lane of a
+            // window counted afresh, the lanes that hold a position of the entering range in a window slid into
+            const bool lane_new = !sliding || !ring_next || tid * ITS + (ITS - 1) >= P.w - (K - 1) - P.inc;
+            ring_next = false;                                  // (true again where this window's scoring loop has run)
+#ifdef FRISK8_EXP_ALLOLD        // (experiment builds, wrong results: nobody gathers - every lane reads the ring)
+            const bool lane_new_exp = false;
+#define lane_new lane_new_exp
+#endif
             slide_next = slide_pp > 0 && ci + 1 < ce && d.kind == 0 && !jump && cand + 1 < d.cand0 + d.ncand &&
                          st + int64_t(P.inc) + P.w <= d.size;
             if (n > NT * ITS) {
@@ -634,9 +676,19 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             };
             // what a max-mer position reads, all of it addressed by the code alone (so it can be fetched ahead of use):
             // genome-side value, the order-8 counters of its 6-mer / 7-mer / itself, the shared-prefix sums
-            struct Fetched { double Ig, A5; uint32_t W5, c8, w7; uint4 w6; };
-            auto fetch = [&](uint32_t c16) __attribute__((always_inline)) -> Fetched {
+            struct Fetched { double Ig, A5; uint32_t W5, c8, w7, roff; uint4 w6; };
+            // (`it`: the lane's position the code belongs to, whose genome-side value waits in the ring - a 1.0 where the position
+            //  starts no max-mer: the stand-in it scores has weight 0, any finite number will do; `score`: a scoring-loop fetch)
+            auto fetch = [&](uint32_t c16, int it = 0, bool score = false) __attribute__((always_inline)) -> Fetched {
                 Fetched f;
+                f.roff = 0;
+                if constexpr (RING) {
+                    f.Ig = 1.0;
+                    if (score) {
+                        f.roff = ring_mine(it);
+                        f.Ig = *reinterpret_cast<const double*>(ring + (lane_new ? (c16 << 3) : f.roff));
+                    }
+                } else {
 #ifdef FRISK8_EXP_IGMASK    // (experiment builds, wrong results: the genome-side gather confined to a small footprint)
                 f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + ((c16 & uint32_t(FRISK8_EXP_IGMASK)) << 3));
 #elif defined(FRISK8_EXP_IGNT)  // (experiment builds: the gather as a non-temporal load)
@@ -647,6 +699,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #else
                 f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^K always
 #endif
+                }
                 if (BITS == 8) {        // the counter of code c is byte c of the table
                     f.c8 = t8b[c16];
                     f.w7 = *reinterpret_cast<const uint32_t*>(t8b + (c16 & ~3u));
@@ -1112,7 +1165,13 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     }
 #pragma unroll
                     for (int k = 0; k < GR; ++k) {
-                        if (!CHECK || g + k < ITS) score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
+                        if (!CHECK || g + k < ITS) {
+                            // (the value this position used, into the ring for the windows to come: 1.0 where it starts no max-mer)
+#ifndef FRISK8_EXP_NOSTORE       // (experiment builds, wrong results: nothing is parked)
+                            if constexpr (RING) *reinterpret_cast<double*>(ring + f[k].roff) = on_at(g + k) ? f[k].Ig : 1.0;
+#endif
+                            score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
+                        }
                     }
                 };
                 // software pipeline: the reads of group g+1 are issued before the arithmetic of group g.
@@ -1122,16 +1181,16 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 if constexpr (ROLLED && ITS % (2 * GR) == 0) {
                     Fetched bufA[GR], bufB[GR];
 #pragma unroll
-                    for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(k));
+                    for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(k), k, true);
 #pragma unroll 1
                     for (int g = 0; g < ITS; g += 2 * GR) {
 #pragma unroll
-                        for (int k = 0; k < GR; ++k) bufB[k] = fetch(code4_at(g + GR + k));
+                        for (int k = 0; k < GR; ++k) bufB[k] = fetch(code4_at(g + GR + k), g + GR + k, true);
                         score_group(bufA, g, std::false_type{});
                         __builtin_amdgcn_sched_barrier(0);
                         const int gn = g + 2 * GR < ITS ? g + 2 * GR : 0;       // (the last trip fetches group 0 again, unused)
 #pragma unroll
-                        for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(gn + k));
+                        for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(gn + k), gn + k, true);
                         score_group(bufB, g + GR, std::false_type{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -1148,12 +1207,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 for (int k = 0; k < D && k < ITS; ++k) igq[k] = ig_at(k);
 #endif
 #pragma unroll
-                for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k));
+                for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k), k, true);
 #pragma unroll
                 for (int g = 0; g < ITS; g += GR) {
                     const int cur = (g / GR) & 1;
 #pragma unroll
-                    for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k));
+                    for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k), g + GR + k, true);
 #ifdef FRISK8_IG_AHEAD
 #pragma unroll
                     for (int k = 0; k < GR; ++k) {
@@ -1204,6 +1263,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             STAMP(7)
             // behind the barrier: nobody reads the tables any more.  The whole order-K table in 16-byte stores (8 / 16 per thread at
             // K = 8) is cheaper than every position clearing its own dword (20 tests, extracts and masked 4-byte stores per lane)
+            ring_next = true;
             remove_fakes();
             if (!slide_next) {          // (a successor that slides takes the table as it stands)
                 if constexpr (CLEAR_ALL) clear_t8();

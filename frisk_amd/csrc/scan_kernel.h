@@ -85,6 +85,7 @@ struct ScanParams {
     int32_t sel_mode, sel_mod;    // scan8_kernel, range mode: 0 all chunks, 1 every sel_mod-th chunk, 2 all the others
     unsigned int* queue;          // scan8_kernel: != nullptr: chunks are dealt by these counters (zero at launch) instead of by block index:
     int32_t queue_n;              // ... queue_n (1 or 8) of them, one per XCD, each over a contiguous share of the chunks
+    double* ig_ring;              // scan8_kernel: per-workgroup ring of genome-side values by window position (see scan8_kernel.h), or nullptr
     int32_t slide_pp;             // scan8_kernel: > 0: inside a chunk the order-K table slides from window to window, this many positions of
                                   // the leaving and of the entering range per thread (= ceil(inc / threads)); 0: every window counted afresh
 };

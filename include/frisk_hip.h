@@ -44,6 +44,9 @@ enum {
 #define FRISK_SCAN_CHUNKS       256u /* schedule the windows in chunks of 8 consecutive candidates whatever the scan's size (a short
                                         scan is otherwise dealt window by window): the path long scans take - tables sliding from
                                         window to window inside a chunk - on inputs of any size.  Results are the same bits. */
+#define FRISK_SCAN_BITS4        512u /* K = 8: the bulk launch with 4-bit counters whatever the scan's size, overflowing windows handed on
+                                        to the 8- and 16-bit forms (a short scan otherwise starts at 8 bits; a long one samples first).
+                                        Results are the same bits. */
 
 /* per-row status bits written to `status` by frisk_scan */
 #define FRISK_ROW_KEPT        1u      /* window passed the < 30 % non-ACGT filter (L237-241)          */

@@ -203,7 +203,7 @@ def test_cli_packed_sequence_cache(tmp_path, capsys):
     assert open(T / "raw_window_scores.bed").read() == first and os.path.getmtime(cache) >= t0
     # the FASTA changes (one more record): the cache is for another file now
     with open(fa, "a") as fh:
-        fh.write(">extra\n" + "ACGT" * 700 + "\n")
+        fh.write(">extra\n" + "ACGGTCA" * 700 + "\n")         # 4 900 bases: long enough for windows of its own
     assert readSeqCache(str(cache), str(fa)) is None
     assert main(argv + ["--recalc"]) == 0
     assert len(open(T / "raw_window_scores.bed").read().splitlines()) > len(first.splitlines())

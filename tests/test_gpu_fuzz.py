@@ -11,8 +11,8 @@ from oracle import frisk_oracle_c as OC
 pytestmark = pytest.mark.gpu
 
 
-def _random_case(rng):
-    kmax = int(rng.integers(1, 9))
+def _random_case(rng, kmax_hi=8):
+    kmax = int(rng.integers(1, kmax_hi + 1))
     kmin = int(rng.integers(1, kmax + 1))
     w = int(rng.choice([37, 64, 100, 333, 512, 1000, 2048, 2049, 5000, 5121, 8192, 8193, 12000, 66000]))
     inc = max(1, int(w * rng.choice([0.05, 0.2, 0.5, 0.9, 1.0, 1.6])))
@@ -76,3 +76,90 @@ def test_random_cases_against_c_oracle(block):
             assert np.max(np.abs(res.kld[k][ok] - exp["kld"][ok])) <= 1e-11, tag
         checked += len(k)
     assert checked > 100
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_cases_up_to_k10(block):
+    """The same differential test with the highest order drawn up to 10 (K = 9, 10: the global-memory kernels), on smaller
+    inputs - those kernels walk 4^K bins per window."""
+    rng = np.random.default_rng(9100 + block)
+    checked = big = 0
+    for case_no in range(12):
+        c = _random_case(rng, kmax_hi=10)
+        if c["kmax"] >= 9:
+            c["w"] = min(c["w"], 5121)
+            c["inc"] = max(1, min(c["inc"], c["w"]))
+            c["seqs"] = [s[:4 * c["w"]] for s in c["seqs"][:3]]
+            big += 1
+        tag = "block %d case %d: k=%d..%d w=%d i=%d lens=%s" % (block, case_no, c["kmin"], c["kmax"], c["w"], c["inc"], [len(s) for s in c["seqs"]])
+        with Engine(c["kmin"], c["kmax"]) as e:
+            e.load(c["seqs"])
+            e.profile_reset(); e.profile_add(mask_host=c["mask_host"]); e.profile_finalize()
+            sym, tl, ex, nn = e.profile_get()
+            osym, ometa = OC.genome_profile(c["seqs"], c["kmin"], c["kmax"], c["mask_host"])
+            assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa), tag
+            res = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"])
+            ig = OC.genome_ivom(osym, ometa, c["kmin"], c["kmax"])
+            exp = OC.scan(c["seqs"], ig, c["kmin"], c["kmax"], c["w"], c["inc"], scaffolds_all=c["scaffolds_all"], rip=c["rip"])
+        k = np.nonzero(res.kept)[0]
+        assert len(k) == len(exp["kld"]), tag
+        if not len(k):
+            continue
+        assert np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.stop[k], exp["stop"]), tag
+        assert np.array_equal(res.gc[k], exp["gc"], equal_nan=True), tag
+        zero = (exp["status"] & OC.ROW_ZERO_DIV) != 0
+        assert np.array_equal((res.status[k] & _ffi.ROW_ZERO_WEIGHT) != 0, zero), tag
+        ok = ~zero
+        if ok.any():
+            assert np.max(np.abs(res.kld[k][ok] - exp["kld"][ok])) <= 1e-11, tag
+        checked += len(k)
+    assert checked > 30 and big >= 1
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_tile_sharding_equals_one_gpu(tmp_path, block):
+    """frisk_fasta_load_shard with random geometry, word sizes, scaffold make-up and world size: the ranks of the job played one
+    after the other give the one-GPU raw profile (summed) and the one-GPU rows (concatenated) bit for bit."""
+    rng = np.random.default_rng(4400 + block)
+    for case_no in range(4):
+        kmax = int(rng.choice([4, 6, 7, 8, 8]))
+        kmin = int(rng.integers(1, max(2, kmax - 2)))
+        w = int(rng.choice([400, 1000, 2000, 5000]))
+        inc = max(1, int(w * rng.choice([0.1, 0.2, 0.5, 1.0, 1.3])))
+        scaffolds_all = bool(rng.integers(0, 2))
+        world = int(rng.choice([2, 3, 5, 8]))
+        fa = tmp_path / ("g%d.fa" % case_no)
+        with open(fa, "wb") as fh:
+            for i in range(int(rng.integers(1, 7))):
+                n = int(rng.choice([0, 7, w // 2, w + 1, 3 * w + 5, 11 * w + int(rng.integers(0, w)), 40 * inc + w]))
+                s = rng.choice(np.frombuffer(b"ATGC", dtype=np.uint8), size=n, p=rng.dirichlet([2, 2, 2, 2]))
+                for _ in range(int(rng.integers(0, 4))):
+                    if n:
+                        a = int(rng.integers(0, n))
+                        ln = int(rng.choice([1, 9, 40, w // 3 + 1]))
+                        if rng.integers(0, 2):
+                            s[a:a + ln] = ord("N")
+                        else:
+                            s[a:a + ln] |= 0x20
+                fh.write(b">scaf%d\n" % i)
+                for o in range(0, n, 61):
+                    fh.write(s[o:o + 61].tobytes() + b"\n")
+        tag = "block %d case %d: k=%d..%d w=%d i=%d all=%s world=%d" % (block, case_no, kmin, kmax, w, inc, scaffolds_all, world)
+        rip = kmin <= 2 <= kmax
+        with Engine(kmin, kmax) as e:
+            e.load_fasta(str(fa))
+            e.profile_reset(); e.profile_add(); whole_raw = e.profile_raw(); e.profile_finalize()
+            full = e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
+            raws, parts = [], []
+            for rank in range(world):
+                _, (c0, c1) = e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all)
+                e.profile_reset(); e.profile_add()
+                raws.append(e.profile_raw())
+            assert np.array_equal(np.sum(raws, axis=0), whole_raw), tag
+            for rank in range(world):
+                e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all)
+                e.profile_set_raw(whole_raw); e.profile_finalize()
+                parts.append(e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all, chunks=bool(rank & 1)))
+            for f in ("seq_index", "start", "stop", "status", "kld", "gc") + (("pi", "si", "cri") if rip else ()):
+                cat = np.concatenate([getattr(p, f) for p in parts])
+                assert np.array_equal(cat, getattr(full, f), equal_nan=True), (tag, f)
