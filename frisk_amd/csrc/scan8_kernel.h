@@ -55,6 +55,9 @@
 #ifndef FRISK8_RING
 #define FRISK8_RING 1               // genome-side values travel from window to window through a per-workgroup ring in global memory (below)
 #endif
+#ifndef FRISK8_PARK_LATE
+#define FRISK8_PARK_LATE 0          // 1: a parking wave stores behind its scoring loop instead of inside it (measured: +-0)
+#endif
 #define FRISK8_RING_COLS 512        // ring geometry: ITS rows x 512 columns of doubles per workgroup (position p <-> row p % ITS, column p / ITS % 512)
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
@@ -678,15 +681,16 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // genome-side value, the order-8 counters of its 6-mer / 7-mer / itself, the shared-prefix sums
             struct Fetched { double Ig, A5; uint32_t W5, c8, w7, roff; uint4 w6; };
             // (`it`: the lane's position the code belongs to, whose genome-side value waits in the ring - a 1.0 where the position
-            //  starts no max-mer: the stand-in it scores has weight 0, any finite number will do; `score`: a scoring-loop fetch)
-            auto fetch = [&](uint32_t c16, int it = 0, bool score = false) __attribute__((always_inline)) -> Fetched {
+            //  starts no max-mer: the stand-in it scores has weight 0, any finite number will do;
+            //  mode: 0 counts only; 1 the scoring loop of a wave whose lanes all read the ring; 2 ... of a wave with lanes that gather)
+            auto fetch = [&](uint32_t c16, int it = 0, int mode = 0) __attribute__((always_inline)) -> Fetched {
                 Fetched f;
                 f.roff = 0;
                 if constexpr (RING) {
                     f.Ig = 1.0;
-                    if (score) {
+                    if (mode) {
                         f.roff = ring_mine(it);
-                        f.Ig = *reinterpret_cast<const double*>(ring + (lane_new ? (c16 << 3) : f.roff));
+                        f.Ig = *reinterpret_cast<const double*>(ring + ((mode == 2 && lane_new) ? (c16 << 3) : f.roff));
                     }
                 } else {
 #ifdef FRISK8_EXP_IGMASK    // (experiment builds, wrong results: the genome-side gather confined to a small footprint)
@@ -1131,8 +1135,18 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #endif
             // ALLON: every lane of this wave starts a max-mer at every one of its positions (three waves in four of a window
             // without invalid bases) - no stand-in code to select, no weight to mask
-            auto score_all = [&](auto allon_c, auto orph_c) __attribute__((always_inline)) {
+            // (PARK: this wave has lanes that gather from the table - it parks what it used in the ring for the windows to come; a
+            //  wave whose lanes all read the ring has nothing new to park, and its loop carries neither the select nor the store.
+            //  Stores cost more than they look in this loop: loads and stores return in order on one counter, so every load behind a
+            //  store waits for the store's acknowledgement - measured 1.1 ms per scan with every wave parking)
+            auto score_all = [&](auto allon_c, auto orph_c, auto park_c) __attribute__((always_inline)) {
                 constexpr bool ALLON = decltype(allon_c)::value;
+                constexpr bool PARK = RING && decltype(park_c)::value;
+                constexpr int FMODE = PARK ? 2 : 1;
+                // the unrolled loop parks behind itself: a store in front of a load holds that load's data back until the store is
+                // acknowledged (one in-order counter), and this wave - the one that gathers - is the one the others wait for
+                constexpr bool PARK_LATE = PARK && FRISK8_PARK_LATE && !(ROLLED_K && ITS % (2 * GR) == 0);
+                double parked[PARK_LATE ? ITS : 1];
                 constexpr int ORPH = decltype(orph_c)::value;           // the orphan list holds <= 2 entries (one (K-1)-mer at most) / <= 4 / any number: 2 / 4 / 0
                 auto on_at = [&](int it) -> bool { return ALLON || ((fm4 >> (31 - it)) & 1u); };
                 auto code4_at = [&](int it) -> uint32_t {      // the position's max-mer, or the stand-in where it starts none
@@ -1168,7 +1182,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         if (!CHECK || g + k < ITS) {
                             // (the value this position used, into the ring for the windows to come: 1.0 where it starts no max-mer)
 #ifndef FRISK8_EXP_NOSTORE       // (experiment builds, wrong results: nothing is parked)
-                            if constexpr (RING) *reinterpret_cast<double*>(ring + f[k].roff) = on_at(g + k) ? f[k].Ig : 1.0;
+                            if constexpr (PARK) {
+                                const double v = on_at(g + k) ? f[k].Ig : 1.0;
+                                if constexpr (PARK_LATE) parked[g + k] = v;      // (unrolled form: stored behind the loop)
+                                else *reinterpret_cast<double*>(ring + f[k].roff) = v;
+                            }
 #endif
                             score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
                         }
@@ -1181,16 +1199,16 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 if constexpr (ROLLED && ITS % (2 * GR) == 0) {
                     Fetched bufA[GR], bufB[GR];
 #pragma unroll
-                    for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(k), k, true);
+                    for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(k), k, FMODE);
 #pragma unroll 1
                     for (int g = 0; g < ITS; g += 2 * GR) {
 #pragma unroll
-                        for (int k = 0; k < GR; ++k) bufB[k] = fetch(code4_at(g + GR + k), g + GR + k, true);
+                        for (int k = 0; k < GR; ++k) bufB[k] = fetch(code4_at(g + GR + k), g + GR + k, FMODE);
                         score_group(bufA, g, std::false_type{});
                         __builtin_amdgcn_sched_barrier(0);
                         const int gn = g + 2 * GR < ITS ? g + 2 * GR : 0;       // (the last trip fetches group 0 again, unused)
 #pragma unroll
-                        for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(gn + k), gn + k, true);
+                        for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(gn + k), gn + k, FMODE);
                         score_group(bufB, g + GR, std::false_type{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -1207,12 +1225,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 for (int k = 0; k < D && k < ITS; ++k) igq[k] = ig_at(k);
 #endif
 #pragma unroll
-                for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k), k, true);
+                for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k), k, FMODE);
 #pragma unroll
                 for (int g = 0; g < ITS; g += GR) {
                     const int cur = (g / GR) & 1;
 #pragma unroll
-                    for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k), g + GR + k, true);
+                    for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k), g + GR + k, FMODE);
 #ifdef FRISK8_IG_AHEAD
 #pragma unroll
                     for (int k = 0; k < GR; ++k) {
@@ -1222,6 +1240,10 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #endif
                     score_group(buf[cur], g, std::true_type{});
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (PARK_LATE) {
+#pragma unroll
+                    for (int it = 0; it < ITS; ++it) *reinterpret_cast<double*>(ring + ring_mine(it)) = parked[it];
                 }
             };
             constexpr uint32_t ALL_MINE = uint32_t(0xFFFFFFFF00000000ull >> ITS);
@@ -1235,18 +1257,21 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
                 acode4 = (uint64_t(ah) << 32) | al;
 #endif
+            const bool wave_parks = RING && __any(lane_new);                // (wave-uniform)
+            using yes = std::true_type;
+            using no = std::false_type;
             if constexpr (PLACE) {
                 if (n_list == 0) {              // (every orphan found room in the table: nearly every window)
-                    if (__all(fm4 == ALL_MINE)) score_all(std::true_type{}, orphX{});
-                    else score_all(std::false_type{}, orphX{});
-                } else if (n_list <= 4) score_all(std::false_type{}, orph4{});
-                else score_all(std::false_type{}, orphN{});
+                    if (__all(fm4 == ALL_MINE)) { if (wave_parks) score_all(yes{}, orphX{}, yes{}); else score_all(yes{}, orphX{}, no{}); }
+                    else { if (wave_parks) score_all(no{}, orphX{}, yes{}); else score_all(no{}, orphX{}, no{}); }
+                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{});
+                else score_all(no{}, orphN{}, yes{});
             } else {
                 if (n_list <= 2 && n7 <= 1) {       // (every window without invalid bases)
-                    if (__all(fm4 == ALL_MINE)) score_all(std::true_type{}, orph2{});
-                    else score_all(std::false_type{}, orph2{});
-                } else if (n_list <= 4) score_all(std::false_type{}, orph4{});
-                else score_all(std::false_type{}, orphN{});
+                    if (__all(fm4 == ALL_MINE)) score_all(yes{}, orph2{}, yes{});
+                    else score_all(no{}, orph2{}, yes{});
+                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{});
+                else score_all(no{}, orphN{}, yes{});
             }
 #ifdef FRISK8_S4_REPEAT
             }

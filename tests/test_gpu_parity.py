@@ -592,8 +592,8 @@ def test_long_scan_in_two_row_segments():
     S = OC.Seqs(seqs)
     osym, ometa = OC.genome_profile(S, 1, 8)
     ig = OC.genome_ivom(osym, ometa, 1, 8)
-    unit = 8 * 16
-    cut = (n // unit - max(1, n // unit // 16)) * unit                      # where frisk_scan cuts (chunks of 8, stride 16)
+    unit = 16 * 16                                                          # (2 i <= w - 7: the tables slide, chunks of 16)
+    cut = (n // unit - max(1, n // unit // 16)) * unit                      # where frisk_scan cuts (whole chunks, stride 16)
     for a, b in ((cut - 1500, cut + 1500), (n - 2000, n), (0, 2000)):
         exp = OC.scan(S, ig, 1, 8, w, inc, cand=(a, b))
         k = a + np.nonzero(res.kept[a:b])[0]
