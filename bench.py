@@ -459,7 +459,19 @@ def main(argv=None):
                                           "rocprofv3 --stats lists the bulk kernel with two launches per scan (about 7.6 ms + "
                                           "0.6 ms, one after the other): its 'average' there is their mean, the scan is their sum",
                          "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
-                                 "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding`"},
+                                 "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding` and `l2_gather`"},
+            # what did bind until round 3: every scored position reads 8 bytes of the 512 KB genome table at a random
+            # place = one 128-byte line from L2.  Modelled line traffic of one scan, before and with the ring (a position's value is
+            # gathered once per chunk of 16 windows and otherwise read coalesced from the workgroup's ring)
+            "l2_gather": (lambda pos, chunk: {
+                "lines_are": "128 B per gathered double (vector L1: 32 KB against a 512 KB table)",
+                "gather_GB_per_scan_without_ring": rows * pos * 128 / 1e9,
+                "time_at_l2_peak_ms_without_ring": rows * pos * 128 / 34.5e12 * 1e3,
+                "l2_peak_TBps": 34.5,
+                "gather_GB_per_scan_with_ring": rows * (pos / chunk + (INC + 3 * 20) * (chunk - 1) / chunk) * 128 / 1e9
+                                                + rows * pos * 8 * 2 / 1e9,
+                "note": "with the ring: one window in %d gathers every position, the others the entering range (inc positions, rounded "
+                        "up to the lanes that hold them) and read / park the rest as coalesced doubles" % chunk})(W - KMAX + 1, 16),
             "binding": binding,
             **({"rehearsal_on_one_gpu": True} if rehearsal else {}),
             "cold": cold,

@@ -245,7 +245,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     // loop has no branch on who is who: the load's offset is a select between two, the store is unconditional.  L2 -> L1 traffic
     // per window: about inc gathers + w coalesced doubles (170 KB) instead of w gathers (640 KB).  Same values, same lanes, same
     // order of summation: same bits.  (The ring lives in L2 / Infinity Cache: 80 KB per workgroup.)
-    constexpr bool RING = FRISK8_RING != 0;
+    // (K = 8 with 4-bit counters only: the 8-bit form - two workgroups per CU - is bound by instruction issue at its occupancy,
+    //  not by the gather: measured 8.80 ms without the ring, 9.06 with it, on the repeat-rich shape; at K = 6, 7 the table is 32 / 128 KB)
+    constexpr bool RING = FRISK8_RING != 0 && KMAX == 8 && BITS == 4;
     // (one buffer: a copy of the genome table first, the workgroups' slices behind it - so that "from the table" and "from the
     //  ring" are two 32-bit offsets from one base, and the scoring loop's load is one instruction either way)
     char* const ring = RING ? reinterpret_cast<char*>(P.ig_ring) : nullptr;
