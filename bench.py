@@ -451,6 +451,10 @@ def main(argv=None):
             "scan_row_segments": row_segments,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
+                         "traffic_note": "bytes at the L2's fabric side per scan (2 x FETCH_SIZE + WRITE_SIZE; Infinity Cache hits included).  Since "
+                                         "round 3 almost all of it is the per-workgroup ring that carries genome-side values from window to window "
+                                         "(61 MB in all: beyond L2, inside the 256 MB Infinity Cache) - traded for a 3.5 x cut of the L2 -> L1 line "
+                                         "traffic that bound the kernel (`l2_gather`)",
                          "kernel": "scan8_kernel: the two bulk launches of a scan (15/16 of the rows, and the last 1/16 on a second stream while the first rows go to the host) + its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them",
                          "algorithmic_bytes_per_launch": b_alg,
                          "bulk_launches_per_scan": row_segments,

@@ -315,9 +315,12 @@ hipError_t launch_scan8(const ScanParams& P, int num_cu, int64_t work_items, hip
 // one launch of the narrow-counter K = 8 kernel: counter width, window class (<= 2048 / <= 5120 bases), debug dump
 hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st,
                          bool sample = false) {
+    const bool slides = P.slide_pp > 0 && P.in_list == nullptr;        // (else: the instantiation without the ring, ROLE bit 1)
     if (sample) {           // the 1/16 sample of the adaptive width: 4-bit counters, its own name in kernel statistics
-        if (small_w) return launch_scan8<8, 256, 8, 4, 64, 3, false, 1>(P, num_cu, work_items, st);
-        return launch_scan8<8, 256, 20, 4, 64, 3, false, 1>(P, num_cu, work_items, st);
+        if (small_w) return slides ? launch_scan8<8, 256, 8, 4, 64, 3, false, 1>(P, num_cu, work_items, st)
+                                   : launch_scan8<8, 256, 8, 4, 64, 3, false, 3>(P, num_cu, work_items, st);
+        return slides ? launch_scan8<8, 256, 20, 4, 64, 3, false, 1>(P, num_cu, work_items, st)
+                      : launch_scan8<8, 256, 20, 4, 64, 3, false, 3>(P, num_cu, work_items, st);
     }
 #define FRISK_L7(K_, ITS_, DBG_) return launch_scan8<K_, 256, ITS_, 8, 64, FRISK_K7_WPS, DBG_>(P, num_cu, work_items, st)
     if (kmax == 7) {        // K = 6, 7: the 8-bit table is 16 / 4 KiB - registers, not LDS, bound the workgroups per CU
@@ -334,6 +337,10 @@ hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const Sca
 #define FRISK_L8(ITS_, BITS_, WPS_, DBG_) return launch_scan8<8, 256, ITS_, BITS_, 64, WPS_, DBG_>(P, num_cu, work_items, st)
     if (bits == 4) {
         if (debug) { if (small_w) FRISK_L8(8, 4, 3, true); else FRISK_L8(20, 4, 3, true); }
+        if (!slides) {
+            if (small_w) return launch_scan8<8, 256, 8, 4, 64, 3, false, 2>(P, num_cu, work_items, st);
+            return launch_scan8<8, 256, 20, 4, 64, 3, false, 2>(P, num_cu, work_items, st);
+        }
         if (small_w) FRISK_L8(8, 4, 3, false);
 #ifdef FRISK8_NT512      // (experiment builds: 512-thread workgroups, three per CU = six waves per SIMD)
         return launch_scan8<8, 512, 10, 4, 64, 6, false>(P, num_cu, work_items, st);

@@ -125,7 +125,7 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
            __builtin_amdgcn_readlane(int(x), 32) + __builtin_amdgcn_readlane(int(x), 48);
 }
 
-// ROLE only names the launch (0 bulk / list, 1 the sample of the adaptive width): the code is the same, but a profiler's
+// ROLE names the launch (bit 0: the sample of the adaptive width, bit 1: no sliding, hence no ring): the code is otherwise the same, but a profiler's
 // per-kernel statistics then keep the 1/16 sample launches apart from the bulk launches.
 // NT threads, windows of at most NT*ITS bases, BITS per order-8 counter, LOGN: bins of the logarithm table, WPS: waves per SIMD the register allocation must allow (= workgroups per
 // CU * NT / 256).
@@ -247,7 +247,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     // order of summation: same bits.  (The ring lives in L2 / Infinity Cache: 80 KB per workgroup.)
     // (K = 8 with 4-bit counters only: the 8-bit form - two workgroups per CU - is bound by instruction issue at its occupancy,
     //  not by the gather: measured 8.80 ms without the ring, 9.06 with it, on the repeat-rich shape; at K = 6, 7 the table is 32 / 128 KB)
-    constexpr bool RING = FRISK8_RING != 0 && KMAX == 8 && BITS == 4;
+    //  ROLE & 2: a launch whose windows do not slide (increment above half a window, or too few windows for chunks): every window
+    //  would gather everything and park it for nobody - such launches take the instantiation without the ring.)
+    constexpr bool RING = FRISK8_RING != 0 && KMAX == 8 && BITS == 4 && !(ROLE & 2);
     // (one buffer: a copy of the genome table first, the workgroups' slices behind it - so that "from the table" and "from the
     //  ring" are two 32-bit offsets from one base, and the scoring loop's load is one instruction either way)
     char* const ring = RING ? reinterpret_cast<char*>(P.ig_ring) : nullptr;
