@@ -342,16 +342,10 @@ hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const Sca
             return launch_scan8<8, 256, 20, 4, 64, 3, false, 2>(P, num_cu, work_items, st);
         }
         if (small_w) FRISK_L8(8, 4, 3, false);
-#ifdef FRISK8_NT512      // (experiment builds: 512-thread workgroups, three per CU = six waves per SIMD)
-        return launch_scan8<8, 512, 10, 4, 64, 6, false>(P, num_cu, work_items, st);
-#endif
         FRISK_L8(20, 4, 3, false);
     }
     if (debug) { if (small_w) FRISK_L8(8, 8, 2, true); else FRISK_L8(20, 8, 2, true); }
     if (small_w) FRISK_L8(8, 8, 2, false);
-#ifdef FRISK8_NT512_8    // (experiment builds: the 8-bit form with 512-thread workgroups, two per CU = four waves per SIMD)
-    return launch_scan8<8, 512, 10, 8, 32, 4, false>(P, num_cu, work_items, st);
-#endif
     FRISK_L8(20, 8, 2, false);
 #undef FRISK_L8
 }

@@ -95,11 +95,7 @@ __device__ inline double log_tab_n(double x, const double2* tab) {
     const double m = __builtin_amdgcn_frexp_mant(x);
     // (the bin's BYTE offset straight from the mantissa's top bits: shift + mask, no index scaling)
     const uint32_t off = (uint32_t(__double2hiint(m)) >> ((N == 128 ? 13 : (N == 64 ? 14 : 15)) - 4)) & (uint32_t(N - 1) << 4);
-#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 1)       // (experiment builds, wrong results: no table read)
-    const double2 e = make_double2(1.0 + double(off) * 0x1p-11, double(off) * -0x1p-11);
-#else
     const double2 e = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
-#endif
     const double r = __builtin_fma(m, e.x, -1.0);
     double p = (DEG & 1) ? 1.0 / DEG : -1.0 / DEG;
 #pragma unroll
@@ -370,10 +366,6 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // window counted afresh, the lanes that hold a position of the entering range in a window slid into
             const bool lane_new = !sliding || !ring_next || tid * ITS + (ITS - 1) >= P.w - (K - 1) - P.inc;
             ring_next = false;                                  // (true again where this window's scoring loop has run)
-#ifdef FRISK8_EXP_ALLOLD        // (experiment builds, wrong results: nobody gathers - every lane reads the ring)
-            const bool lane_new_exp = false;
-#define lane_new lane_new_exp
-#endif
             slide_next = slide_pp > 0 && ci + 1 < ce && d.kind == 0 && !jump && cand + 1 < d.cand0 + d.ncand &&
                          st + int64_t(P.inc) + P.w <= d.size;
             if (n > NT * ITS) {
@@ -697,16 +689,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         f.Ig = *reinterpret_cast<const double*>(ring + ((mode == 2 && lane_new) ? (c16 << 3) : f.roff));
                     }
                 } else {
-#ifdef FRISK8_EXP_IGMASK    // (experiment builds, wrong results: the genome-side gather confined to a small footprint)
-                f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + ((c16 & uint32_t(FRISK8_EXP_IGMASK)) << 3));
-#elif defined(FRISK8_EXP_IGNT)  // (experiment builds: the gather as a non-temporal load)
-                f.Ig = __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3)));
-#elif defined(FRISK8_IG_AHEAD)
-                f.Ig = 0.0;                                                                      // (comes from the look-ahead queue)
-                if (ROLLED_K) f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));
-#else
                 f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^K always
-#endif
                 }
                 if (BITS == 8) {        // the counter of code c is byte c of the table
                     f.c8 = t8b[c16];
@@ -719,16 +702,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #else
                     f.w7 = 0;
 #endif
-#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 2)
-                    const uint2 x = make_uint2(0x11111111u, c16 | 0x1111u);
-#else
                     const uint2 x = *reinterpret_cast<const uint2*>(t8b + ((c16 >> 4) << 3));
-#endif
                     f.w6 = make_uint4(x.x, x.y, 0u, 0u);
                 }
-#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 4)
-                if (true) { f.W5 = c16 | 1024u; f.A5 = double(c16 >> 6) + 1.0; } else
-#endif
                 if (FRISK8_PRE_SPLIT) {
                     f.W5 = *reinterpret_cast<const uint32_t*>(lds + L::pre + NL * 8 + ((c16 >> 6) << 2));
                     f.A5 = *reinterpret_cast<const double*>(lds + L::pre + ((c16 >> 6) << 3));
@@ -1079,11 +1055,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             auto score_one = [&](const Fetched& f, uint32_t c8, uint32_t c7, uint32_t c6, uint32_t sel, bool on)
                                  __attribute__((always_inline)) {
                 double2 rs;                                                   // {1/c8 (1.0 for the 19 in 20 max-mers seen once), c8^2 r8}
-#if defined(FRISK8_EXP_NOLDS) && (FRISK8_EXP_NOLDS & 8)
-                if constexpr (BITS == 4) rs = make_double2(1.0, r8 * double(sel & 15u));
-#else
                 if constexpr (BITS == 4) rs = rstab[sel & 15u];
-#endif
                 else {
                     rs = make_double2(rctab[sel & 15u], double(__umul24(sel, sel)) * r8);     // (the same product, rounded alike)
                     if (__builtin_expect(__any(c8 >= 16u), 0)) {              // (wave-uniform, rare: low-complexity sequence)
@@ -1121,7 +1093,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // code variants of stage 1 alive across the whole window (60 registers) instead of re-deriving them here
             uint32_t ah = uint32_t(acode >> 32), al = uint32_t(acode), fm4 = fullm;
             asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
-            uint64_t acode4 = (uint64_t(ah) << 32) | al;
+            const uint64_t acode4 = (uint64_t(ah) << 32) | al;
             auto raw4_at = [&](int it) -> uint32_t { return uint32_t(acode4 >> (64 - 2 * K - 2 * it)) & (NK - 1u); };
             // Shape of the scoring loop, measured per K (bench shard / C2 shape, M windows/s):
             //   K = 8 (LDS allows 3 / 2 workgroups per CU): unrolled, groups of 2: 44.8 / 36.2; rolled, groups of 1: 43.2 / 35.6
@@ -1185,13 +1157,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     for (int k = 0; k < GR; ++k) {
                         if (!CHECK || g + k < ITS) {
                             // (the value this position used, into the ring for the windows to come: 1.0 where it starts no max-mer)
-#ifndef FRISK8_EXP_NOSTORE       // (experiment builds, wrong results: nothing is parked)
                             if constexpr (PARK) {
                                 const double v = on_at(g + k) ? f[k].Ig : 1.0;
                                 if constexpr (PARK_LATE) parked[g + k] = v;      // (unrolled form: stored behind the loop)
                                 else *reinterpret_cast<double*>(ring + f[k].roff) = v;
                             }
-#endif
                             score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
                         }
                     }
@@ -1219,15 +1189,6 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     return;
                 }
                 Fetched buf[2][GR];
-#ifdef FRISK8_IG_AHEAD
-                // the genome-side gathers run FRISK8_IG_AHEAD positions ahead of the arithmetic (the table reads: one group ahead): a
-                // gather that misses L1 takes far longer than a group's arithmetic
-                constexpr int D = FRISK8_IG_AHEAD;
-                double igq[ITS];
-                auto ig_at = [&](int it) -> double { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (code4_at(it) << 3)); };
-#pragma unroll
-                for (int k = 0; k < D && k < ITS; ++k) igq[k] = ig_at(k);
-#endif
 #pragma unroll
                 for (int k = 0; k < GR; ++k) if (k < ITS) buf[0][k] = fetch(code4_at(k), k, FMODE);
 #pragma unroll
@@ -1235,13 +1196,6 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     const int cur = (g / GR) & 1;
 #pragma unroll
                     for (int k = 0; k < GR; ++k) if (g + GR + k < ITS) buf[cur ^ 1][k] = fetch(code4_at(g + GR + k), g + GR + k, FMODE);
-#ifdef FRISK8_IG_AHEAD
-#pragma unroll
-                    for (int k = 0; k < GR; ++k) {
-                        if (g + k + D < ITS) igq[g + k + D] = ig_at(g + k + D);
-                        if (g + k < ITS) buf[cur][k].Ig = igq[g + k];
-                    }
-#endif
                     score_group(buf[cur], g, std::true_type{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1255,12 +1209,6 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             using orph2 = std::integral_constant<int, 2>;
             using orph4 = std::integral_constant<int, 4>;
             using orphN = std::integral_constant<int, 0>;
-#ifdef FRISK8_S4_REPEAT      // (experiment builds: the scoring loop 0 / 2 / 3 times - what a window costs without it, and what one more costs)
-#pragma unroll 1
-            for (int rep = 0; rep < FRISK8_S4_REPEAT; ++rep) {
-                asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
-                acode4 = (uint64_t(ah) << 32) | al;
-#endif
             const bool wave_parks = RING && __any(lane_new);                // (wave-uniform)
             using yes = std::true_type;
             using no = std::false_type;
@@ -1277,9 +1225,6 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 } else if (n_list <= 4) score_all(no{}, orph4{}, yes{});
                 else score_all(no{}, orphN{}, yes{});
             }
-#ifdef FRISK8_S4_REPEAT
-            }
-#endif
 
             // workgroup totals in a fixed order: DPP butterfly per wave, then the NW partials in wave order
 #if FRISK8_PRIO
