@@ -28,6 +28,11 @@
 //               stand-in (a real max-mer of the window) with weight 0: no masks.
 //   * work      chunks of 8 consecutive windows, dealt by one counter per XCD (a workgroup takes the next chunk when it is
 //               done with its last; neighbouring chunks stay on one L2; an XCD that has run dry takes from the next one).
+//   * round 3    inside a chunk of 16 consecutive windows the order-K table SLIDES (2 inc updates per window instead of w - K + 1 and a
+//               cleared table); orphans are FOLDED INTO THE TABLE as max-mers that do not occur (no orphan compares in stage 4); and the
+//               genome-side value of a position travels from window to window through a per-workgroup RING in global memory instead of
+//               being gathered - a whole L2 line per 8 bytes - by every window that covers it: that gather's L2 -> L1 traffic was what
+//               the kernel was bound by.  Each is described where it is implemented; measurements: DESIGN.md section 3.3a.
 // Windows up to NT*ITS bases, kmin <= K-3 (the shared prefix level); everything else stays on scan_kernel.h.
 // Measurements, the adaptive choice between 4 and 8 bits, and what was tried and dropped: DESIGN.md section 3.3.
 #pragma once

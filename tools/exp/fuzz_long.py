@@ -57,7 +57,8 @@ for seed in range(seed0, seed0 + nseeds):
         e.load(seqs)
         e.profile_reset(); e.profile_add(); e.profile_finalize()
         sym, tl, ex, nn = e.profile_get()
-        res = e.scan(w, inc, rip=rip, scaffolds_all=all_)
+        # (round 3: the schedule of a long scan - chunks, sliding tables, the ring - on every case; 4-bit counters first on odd seeds)
+        res = e.scan(w, inc, rip=rip, scaffolds_all=all_, chunks=True, bits4=bool(seed & 1) and kmax == 8)
         stat = e.scan_stat()
     osym, ometa = OC.genome_profile(seqs, kmin, kmax)
     ok = np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
