@@ -509,7 +509,7 @@ void frisk_destroy(frisk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->bat[0].release(); c->bat[1].release();
-    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_logtab64.release(); c->d_logtab32.release(); c->d_rctab.release(); c->d_ovf_list.release(); c->d_ovf_list2.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
+    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_logtab64.release(); c->d_logtab32.release(); c->d_rctab.release(); c->d_ig_ring.release(); c->d_ovf_list.release(); c->d_ovf_list2.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
     c->o_ivom.release(); c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
@@ -1233,12 +1233,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         // counters first, and the share of it that had to be handed on decides the width for the other fifteen.  All three
         // forms give the same bits for a window (same arithmetic; 16-bit only ever sees the windows that wrap 8 bits), so
         // results do not depend on the choice, on the grid, or on the candidate range.
-        // the ring through which genome-side values travel from window to window (scan8_kernel.h): one slice per workgroup of the
-        // largest grid these kernels are launched with (four 256-thread workgroups per CU at K = 6, 7), 20 rows of 512 columns
-        // ... behind a copy of the genome table itself (one base address for both, scan8_kernel.h)
-        HIPC(c, c->d_ig_ring.reserve(nk + size_t(c->num_cu) * 4 * 20 * FRISK8_RING_COLS));
-        HIPC(c, hipMemcpyAsync(c->d_ig_ring.p, c->d_ig.p, nk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        P.ig_ring = c->d_ig_ring.p;
+        P.ig_ring = nullptr;        // (the ring of scan8_kernel.h: allocated below, where the launch's shape is known)
         HIPC(c, c->d_ovf_list.reserve(N));
         HIPC(c, c->d_ovf_list2.reserve(N));
         HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 64 * sizeof(unsigned int), c->stream));
@@ -1252,6 +1247,15 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         // inside a chunk the order-K table slides from window to window where two windows share more than half their bases
         // (2 inc updates instead of w - K + 1 and a cleared table; scan8_kernel.h)
         if (can_slide && chunk8 >= 2) P.slide_pp = int32_t((inc + 255) / 256);
+        // the ring through which genome-side values travel from window to window (scan8_kernel.h): a copy of the genome table (one
+        // base address for both) followed by one slice of 20 rows x 512 columns per workgroup launched.  Only the K = 8 / 4-bit
+        // instantiations with the ring read it: launches whose windows slide, and the debug form
+        if (narrow8 && (P.slide_pp > 0 || debug)) {
+            const size_t slices = size_t(std::min<int64_t>(std::max<int64_t>((n + chunk8 - 1) / chunk8, 1), int64_t(c->num_cu) * 4));
+            HIPC(c, c->d_ig_ring.reserve(nk + slices * 20 * FRISK8_RING_COLS));
+            HIPC(c, hipMemcpyAsync(c->d_ig_ring.p, c->d_ig.p, nk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            P.ig_ring = c->d_ig_ring.p;
+        }
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
         // chunks dealt by counters (scan8_kernel.h) where a chunk is long enough to pay for the exchange: a short scan keeps the static deal
         const bool dealt = chunk8 >= 4;
