@@ -1276,9 +1276,10 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             unsigned int handed = 0;
             HIPC(c, hipMemcpyAsync(&handed, c->d_ovf_count.p, sizeof(handed), hipMemcpyDeviceToHost, c->stream));
             HIPC(c, hipStreamSynchronize(c->stream));
-            // 4-bit pays while fewer than about one window in five has to be redone (measured: 20 ns per window with
-            // 4-bit counters, 25 ns with 8-bit; redoing costs another 25)
-            bulk = (double(handed) <= 0.2 * double(nsample * chunk8)) ? 4 : 8;
+            // 4-bit pays while fewer than about three windows in ten have to be redone (round 3, bench shard with simple repeats at
+            // 0.05 / 0.1 / 0.2 / 0.3 per kb = 10 / 20 / 37 / 51 % of the scored windows handed on: 4-bit bulk 7.27 / 7.96 / 8.97 /
+            // 9.98 ms, 8-bit bulk 8.51 / 8.57 / 8.71 / 8.78 ms - tools/exp/width_sweep.sh)
+            bulk = (double(handed) <= 0.3 * double(nsample * chunk8)) ? 4 : 8;
             sel_mode = 2;
             RB.width_hint = bulk; RB.hint_w = w; RB.hint_inc = inc;
             // the sample's own hand-overs now (list 1 -> 8-bit -> list 2 -> 16-bit), so that lists and counters are free for

@@ -241,11 +241,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     // slid into: the lanes that hold its entering range - and parked in a ring in global memory that belongs to this workgroup,
     // indexed by the position in the scaffold: row = p % ITS, column = p / ITS % 512.  The other lanes read ring[p] instead of
     // Ig[code]: for a fixed step `it` of the scoring loop the lanes' positions are ITS apart, i.e. the same row and consecutive
-    // columns - 512 contiguous bytes per wave instruction instead of 64 lines.  Every lane writes the value it used back (a lane
-    // that read the ring rewrites what it read; a position that starts no max-mer parks a 1.0 - its stand-in has weight 0), so the
-    // loop has no branch on who is who: the load's offset is a select between two, the store is unconditional.  L2 -> L1 traffic
-    // per window: about inc gathers + w coalesced doubles (170 KB) instead of w gathers (640 KB).  Same values, same lanes, same
-    // order of summation: same bits.  (The ring lives in L2 / Infinity Cache: 80 KB per workgroup.)
+    // columns - 512 contiguous bytes per wave instruction instead of 64 lines.  A wave with lanes that gather parks what its lanes
+    // used (a lane that read the ring rewrites what it read; a position that starts no max-mer parks a 1.0 - its stand-in has
+    // weight 0): its copy of the loop has no branch on who is who - the load's offset is a select between two, the store is
+    // unconditional; a wave whose lanes all read the ring runs a copy with neither (stage 4).  L2 -> L1 traffic per window: about
+    // inc gathers + w coalesced doubles (170 KB) instead of w gathers (640 KB).  Same values, same lanes, same order of
+    // summation: same bits.  (The ring lives in the Infinity Cache: 80 KB per workgroup, more in all than L2 holds.)
     // (K = 8 with 4-bit counters only: the 8-bit form - two workgroups per CU - is bound by instruction issue at its occupancy,
     //  not by the gather: measured 8.80 ms without the ring, 9.06 with it, on the repeat-rich shape; at K = 6, 7 the table is 32 / 128 KB)
     //  ROLE & 2: a launch whose windows do not slide (increment above half a window, or too few windows for chunks): every window
