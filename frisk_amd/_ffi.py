@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRISK_HIP_LIB") or os.path.join(_HERE, "libfrisk_hip.so")   # override: kernel experiments
 
-OK, E_ARG, E_HIP, E_STATE, E_CAP, E_ZERO_WEIGHT = 0, -1, -2, -3, -4, -5
+OK, E_ARG, E_HIP, E_STATE, E_CAP, E_ZERO_WEIGHT, E_INDEX = 0, -1, -2, -3, -4, -5, -6
 SCAN_RIP, SCAN_SCAFFOLDS_ALL, SCAN_CHUNKS, SCAN_BITS4 = 1, 2, 256, 512
 ROW_KEPT, ROW_ZERO_WEIGHT, ROW_JUMPBACK, ROW_NO_MAXMER = 1, 2, 4, 8
 
@@ -33,6 +33,11 @@ SYMBOLS = [
     ("frisk_fasta_digest", C.c_int, [C.c_char_p, C.POINTER(C.c_int32), _I64P, C.POINTER(C.c_uint64)]),
     ("frisk_fasta_load_shard", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), _I64P, _I64P, _I64P]),
+    ("frisk_fasta_load_shard_indexed", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
+                                                 C.POINTER(C.c_int32), _I64P, _I64P, _I64P]),
+    ("frisk_fasta_index_build", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_int32]),
+    ("frisk_fasta_index_read", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, _P, C.POINTER(C.c_int32), _I64P,
+                                         C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]),
     ("frisk_seq_count", C.c_int32, [_P]),
     ("frisk_seq_name", C.c_char_p, [_P, C.c_int32]),
     ("frisk_seq_len", C.c_int64, [_P, C.c_int32]),

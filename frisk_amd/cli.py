@@ -228,6 +228,32 @@ def _main(argv=None):
                  use_cache=bool(args.recalc))
     clock.lap("startup (imports + HIP context)")
     table = None
+    index_writers = []
+
+    # Sharded jobs: a rank with a seek index of the FASTA (fasta_index.h; in --tempDir, or beside the file) copies the bytes of
+    # its tiles instead of parsing all of it.  --recalc (store_false: recompute) ignores an index of ours; where a rank had to
+    # parse, rank 0 writes the index beside the other caches for the next run - in the background, it is not needed by this one.
+    def _shard_index(fasta):
+        from .fasta import fastaIndexPaths
+        paths = fastaIndexPaths(fasta, args.tempDir)
+        return paths if args.recalc else paths[2:]
+
+    def _note_shard_load(fasta):
+        if hp.engine.shard_index is not None:
+            log.info("Read this rank's tiles of %s through the index %s", fasta, hp.engine.shard_index)
+        elif rank == 0:
+            import threading
+            from .fasta import fastaIndexPaths, writeFastaIndex
+
+            def _write(src=fasta, dst=fastaIndexPaths(fasta, args.tempDir)[0]):
+                try:
+                    writeFastaIndex(src, dst)
+                except Exception as err:            # (a read-only --tempDir, a vanished file: the next run parses again)
+                    log.info("No seek index written for %s: %s", src, err)
+            th = threading.Thread(target=_write, name="frisk-fasta-index", daemon=True)
+            th.start()
+            index_writers.append(th)
+
     try:
         # ---- phase A: host k-mer profile (L1436-1447); --recalc is store_false: giving it forces recomputation.
         # Under torchrun every rank takes the same branch (the cache is a file all ranks see); rank 0 writes it.
@@ -241,7 +267,9 @@ def _main(argv=None):
         else:
             log.info("Calculating kmers for host sequence: %s", args.hostSeq)
             if sharded:
-                resident_names = D.profile_sharded(hp.engine, args.hostSeq, w, inc, mask_host=args.maskHost, scaffolds_all=all_)
+                resident_names = D.profile_sharded(hp.engine, args.hostSeq, w, inc, mask_host=args.maskHost, scaffolds_all=all_,
+                                                   index=_shard_index(args.hostSeq))
+                _note_shard_load(args.hostSeq)
                 genomeKmers = hp.profileMaps() if rank == 0 else None
             else:
                 hp._load(args.hostSeq)
@@ -267,7 +295,9 @@ def _main(argv=None):
                 if sharded:
                     same = querySeq == args.hostSeq and resident_names is not None
                     table, failed = D.scan_sharded(hp.engine, querySeq, w, inc, rip=rip, scaffolds_all=all_,
-                                                   resident_names=resident_names if same else None)
+                                                   resident_names=resident_names if same else None, index=_shard_index(querySeq))
+                    if not same:
+                        _note_shard_load(querySeq)
                     if failed:
                         zero = ZeroDivisionError("float division by zero")          # on EVERY rank (L437)
                 else:
@@ -285,6 +315,8 @@ def _main(argv=None):
                 _dump_window_cache(windowsPickle, table)
                 clock.lap("window pickle")
     finally:
+        for th in index_writers:
+            th.join()
         hp.close()
     if rank != 0:
         return 0

@@ -23,6 +23,7 @@
 #include "scan_big_kernel.h"
 #include "synth_kernel.h"
 #include "table_text.h"
+#include "fasta_index.h"
 #include "fasta_reader.h"
 
 #ifndef FRISK_K7_WPS
@@ -659,6 +660,30 @@ int frisk_fasta_digest(const char* path, int32_t* n_seq, int64_t* total_len, uin
     return FRISK_OK;
 }
 
+// common tail of the two shard loaders: the tiles' ASCII is on the device; pack it and remember what the tiles are
+static int finish_tiled(frisk_ctx* c, const std::vector<frisk_ctx::Batch::Tile>& tiles, const std::vector<std::string>& names,
+                        const std::vector<int64_t>& lens, int32_t w, int32_t inc, uint32_t flags, int64_t c0, int64_t c1,
+                        int32_t* n_seq_out, int64_t* total_len_out, int64_t* cand_begin, int64_t* cand_end) {
+    frisk_ctx::Batch& B = c->b();
+    int rc = alloc_packed(c);
+    if (rc) return rc;
+    rc = run_pack(c);
+    if (rc) return rc;
+    B.tiled = true;
+    B.tiles = tiles;
+    B.tile_w = w; B.tile_inc = inc; B.tile_flags = flags & FRISK_SCAN_SCAFFOLDS_ALL;
+    B.cand_begin = c0; B.cand_end = c1;
+    B.g_name = names;
+    B.g_len = lens;
+    int64_t total = 0;
+    for (int64_t v : lens) total += v;
+    if (n_seq_out) *n_seq_out = int32_t(lens.size());
+    if (total_len_out) *total_len_out = total;
+    if (cand_begin) *cand_begin = c0;
+    if (cand_end) *cand_end = c1;
+    return FRISK_OK;
+}
+
 int frisk_fasta_load_shard(frisk_ctx* c, const char* path, int32_t w, int32_t inc, uint32_t flags, int32_t rank, int32_t world,
                            int32_t* n_seq_out, int64_t* total_len_out, int64_t* cand_begin, int64_t* cand_end) {
     if (!c || !path) return FRISK_E_ARG;
@@ -693,23 +718,87 @@ int frisk_fasta_load_shard(frisk_ctx* c, const char* path, int32_t w, int32_t in
         if (rc) return rc;
     }
     HIPC(c, hipStreamSynchronize(c->stream));          // (the parser's buffer goes away with this call)
-    rc = alloc_packed(c);
-    if (rc) return rc;
-    rc = run_pack(c);
-    if (rc) return rc;
-    B.tiled = true;
-    B.tiles = tiles;
-    B.tile_w = w; B.tile_inc = inc; B.tile_flags = flags & FRISK_SCAN_SCAFFOLDS_ALL;
-    B.cand_begin = c0; B.cand_end = c1;
-    B.g_name = names;
-    B.g_len = lens;
-    int64_t total = 0;
-    for (int64_t v : lens) total += v;
-    if (n_seq_out) *n_seq_out = int32_t(lens.size());
-    if (total_len_out) *total_len_out = total;
-    if (cand_begin) *cand_begin = c0;
-    if (cand_end) *cand_end = c1;
+    return finish_tiled(c, tiles, names, lens, w, inc, flags, c0, c1, n_seq_out, total_len_out, cand_begin, cand_end);
+}
+
+// ---- the same from a seek index: the rank maps the file and copies the bytes of ITS tiles, nothing else (fasta_index.h) ----
+int frisk_fasta_index_build(const char* fasta_path, const char* index_path, int32_t* n_seq, char* why, int32_t why_cap) {
+    if (!fasta_path || !index_path) return FRISK_E_ARG;
+    auto say = [&](const std::string& m) { if (why && why_cap > 0) { std::strncpy(why, m.c_str(), size_t(why_cap) - 1); why[why_cap - 1] = 0; } };
+    say("");
+    frisk_fasta::MappedFile f(fasta_path);
+    if (!f.good) { say(std::string("cannot open FASTA file: ") + fasta_path); return FRISK_E_ARG; }
+    std::vector<frisk_fasta::FaiEntry> idx;
+    std::string msg;
+    if (!frisk_fasta::build_index(f, idx, msg)) { say(msg); return FRISK_E_INDEX; }
+    if (!frisk_fasta::write_index(index_path, f, idx, msg)) { say(msg); return FRISK_E_ARG; }
+    if (n_seq) *n_seq = int32_t(idx.size());
     return FRISK_OK;
+}
+
+int frisk_fasta_index_read(const char* fasta_path, const char* index_path, int32_t seq_index, int64_t pos0, int64_t n, uint8_t* out,
+                           int32_t* n_seq, int64_t* seq_len, char* name, int32_t name_cap, char* why, int32_t why_cap) {
+    if (!fasta_path || !index_path) return FRISK_E_ARG;
+    auto say = [&](const std::string& m) { if (why && why_cap > 0) { std::strncpy(why, m.c_str(), size_t(why_cap) - 1); why[why_cap - 1] = 0; } };
+    say("");
+    frisk_fasta::MappedFile f(fasta_path);
+    if (!f.good) { say(std::string("cannot open FASTA file: ") + fasta_path); return FRISK_E_ARG; }
+    std::vector<frisk_fasta::FaiEntry> idx;
+    std::string msg;
+    if (!frisk_fasta::read_index(index_path, f, idx, msg)) { say(msg); return FRISK_E_INDEX; }
+    if (n_seq) *n_seq = int32_t(idx.size());
+    if (seq_index < 0) return FRISK_OK;                 // (the count alone)
+    if (size_t(seq_index) >= idx.size()) { say("record index out of range"); return FRISK_E_ARG; }
+    const frisk_fasta::FaiEntry& r = idx[size_t(seq_index)];
+    if (seq_len) *seq_len = r.len;
+    if (name && name_cap > 0) { std::strncpy(name, r.name.c_str(), size_t(name_cap) - 1); name[name_cap - 1] = 0; }
+    if (n > 0) {
+        if (!out || pos0 < 0 || pos0 + n > r.len) { say("range outside the record"); return FRISK_E_ARG; }
+        frisk_fasta::read_range(f, r, pos0, n, out);
+    }
+    return FRISK_OK;
+}
+
+int frisk_fasta_load_shard_indexed(frisk_ctx* c, const char* path, const char* index_path, int32_t w, int32_t inc, uint32_t flags,
+                                   int32_t rank, int32_t world, int32_t* n_seq_out, int64_t* total_len_out, int64_t* cand_begin,
+                                   int64_t* cand_end) {
+    if (!c || !path || !index_path) return FRISK_E_ARG;
+    if (w < 1 || inc < 1) return fail(c, FRISK_E_ARG, "window length and increment must be >= 1");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, FRISK_E_ARG, "rank outside [0, world)");
+    frisk_fasta::MappedFile f(path);
+    if (!f.good) return fail(c, FRISK_E_ARG, std::string("cannot open FASTA file: ") + path);
+    std::vector<frisk_fasta::FaiEntry> idx;
+    std::string msg;
+    if (!frisk_fasta::read_index(index_path, f, idx, msg)) return fail(c, FRISK_E_INDEX, msg);
+    std::vector<int64_t> lens(idx.size());
+    std::vector<std::string> names(idx.size());
+    for (size_t s = 0; s < idx.size(); ++s) { lens[s] = idx[s].len; names[s] = idx[s].name; }
+    HIPC(c, hipSetDevice(c->device));
+    int64_t c0 = 0, c1 = 0;
+    std::vector<frisk_ctx::Batch::Tile> tiles = plan_tiles(lens, w, inc, (flags & FRISK_SCAN_SCAFFOLDS_ALL) != 0, c->kmax, rank, world, c0, c1);
+    std::vector<int64_t> tlen(tiles.size());
+    for (size_t t = 0; t < tiles.size(); ++t) tlen[t] = tile_end(tiles[t], w, inc, c->kmax) - tiles[t].base0;
+    int rc = layout_batch(c, tlen.data(), int32_t(tiles.size()));
+    if (rc) return rc;
+    frisk_ctx::Batch& B = c->b();
+    // the batch as it will sit on the device, assembled on the host from the mapping (PAD between the tiles), one upload
+    frisk_fasta::ByteVec host;
+    host.resize(size_t(B.padded_len));
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int threads = int(std::max(1u, std::min(32u, (hw ? hw : 1u) / unsigned(world))));
+    int64_t pos = 0;
+    for (size_t t = 0; t < tiles.size(); ++t) {
+        const int64_t off = B.seq_off[t];
+        std::memset(host.data() + pos, FRISK_PAD_BYTE, size_t(off - pos));
+        if (tlen[t] > 0) frisk_fasta::read_range_mt(f, idx[size_t(tiles[t].scaf)], tiles[t].base0, tlen[t], host.data() + off, threads);
+        pos = off + (tlen[t] > 0 ? tlen[t] : 0);
+    }
+    std::memset(host.data() + pos, FRISK_PAD_BYTE, size_t(B.padded_len - pos));
+    HIPC(c, B.d_ascii.reserve(size_t(B.padded_len)));
+    rc = h2d(c, B.d_ascii.p, host.data(), size_t(B.padded_len), c->stream);
+    if (rc) return rc;
+    HIPC(c, hipStreamSynchronize(c->stream));          // (the host copy goes away with this call)
+    return finish_tiled(c, tiles, names, lens, w, inc, flags, c0, c1, n_seq_out, total_len_out, cand_begin, cand_end);
 }
 
 int32_t frisk_seq_count(const frisk_ctx* c) {

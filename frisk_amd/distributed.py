@@ -239,14 +239,15 @@ def _gather_table(dist, group, rank, world, res, names, rip):
     return table, bool(flag[0])
 
 
-def profile_sharded(engine, host_path, w, inc, mask_host=False, scaffolds_all=False, group=None):
+def profile_sharded(engine, host_path, w, inc, mask_host=False, scaffolds_all=False, group=None, index=None):
     """Phase A of one job on this rank (computeKmers genomeMode, L1442): keep the rank's tiles of the host FASTA resident,
     count the k-mers that start in the positions it owns, join the ONE all-reduce, finalise.  Every rank ends with the whole
-    genome's profile.  Returns the names of the FASTA's records."""
+    genome's profile.  `index`: seek indices to try (fasta.fastaIndexPaths) - with one a rank reads its tiles' bytes only.
+    Returns the names of the FASTA's records."""
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    names, _ = engine.load_fasta_shard(host_path, w, inc, rank, world, scaffolds_all)
+    names, _ = engine.load_fasta_shard(host_path, w, inc, rank, world, scaffolds_all, index=index)
     engine.profile_reset()
     engine.profile_add(mask_host=mask_host)
     engine.profile_allreduce(group)
@@ -254,7 +255,7 @@ def profile_sharded(engine, host_path, w, inc, mask_host=False, scaffolds_all=Fa
     return names
 
 
-def scan_sharded(engine, query_path, w, inc, rip=False, scaffolds_all=False, group=None, resident_names=None):
+def scan_sharded(engine, query_path, w, inc, rip=False, scaffolds_all=False, group=None, resident_names=None, index=None):
     """Phase B (loop L1478-1494): scan the rank's candidate range of the query FASTA (its tiles are loaded here unless
     `resident_names` says the query's tiles are resident already), gather on rank 0.  Returns (ScoreTable | None, zero_weight)."""
     dist = _dist()
@@ -262,20 +263,20 @@ def scan_sharded(engine, query_path, w, inc, rip=False, scaffolds_all=False, gro
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     names = resident_names
     if names is None:
-        names, _ = engine.load_fasta_shard(query_path, w, inc, rank, world, scaffolds_all)
+        names, _ = engine.load_fasta_shard(query_path, w, inc, rank, world, scaffolds_all, index=index)
     res = engine.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
     return _gather_table(dist, group, rank, world, res, names, rip)
 
 
 def run_sharded_files(engine, host_path, w, inc, mask_host=False, rip=False, scaffolds_all=False, group=None,
-                      query_path=None):
+                      query_path=None, index=None, query_index=None):
     """One whole job straight from FASTA files, N ranks: window-tile sharding with halo - every rank parses the file with the
     native reader but keeps resident (and uploads) only the bases of ITS candidate windows and of the positions it counts;
     one all-reduce; rows gathered on rank 0.  Rows as `run_sharded` (rank 0; None elsewhere)."""
-    names = profile_sharded(engine, host_path, w, inc, mask_host, scaffolds_all, group)
+    names = profile_sharded(engine, host_path, w, inc, mask_host, scaffolds_all, group, index=index)
     same = query_path is None or query_path == host_path
     table, _zero = scan_sharded(engine, query_path or host_path, w, inc, rip, scaffolds_all, group,
-                                resident_names=names if same else None)
+                                resident_names=names if same else None, index=index if same else query_index)
     if table is None:
         return None
     return [r[:3] + (1,) + r[3:] for r in table.rows()]         # (name, start, stop, status, kld, gc[, pi, si, cri])

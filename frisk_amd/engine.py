@@ -56,6 +56,7 @@ class Engine:
         self.nprof = int(self._lib.frisk_profile_len(self._ctx))
         self.n_seq = 0
         self.seq_lens = []
+        self.shard_index = None     # the seek index the last load_fasta_shard used (None: it parsed the file)
         self._pinned = {}           # name -> (address, nbytes): page-locked result buffers, reused across scans
 
     # ------------------------------------------------------------------ lifetime
@@ -171,14 +172,28 @@ class Engine:
         self.seq_lens = [int(self._lib.frisk_seq_len(self._ctx, i)) for i in range(self.n_seq)]
         return [self._lib.frisk_seq_name(self._ctx, i).decode("ascii", "replace") for i in range(self.n_seq)]
 
-    def load_fasta_shard(self, path, w, inc, rank, world, scaffolds_all=False):
-        """One rank's share of a multi-GPU job (window tiles + halo): parse the file natively, keep resident only the bases
-        of the rank's candidate windows and of the positions it counts.  Returns (names of ALL records, (cand_begin, cand_end)):
-        scan() on this batch numbers candidates from 0 = cand_begin."""
+    def load_fasta_shard(self, path, w, inc, rank, world, scaffolds_all=False, index=None):
+        """One rank's share of a multi-GPU job (window tiles + halo): keep resident only the bases of the rank's candidate
+        windows and of the positions it counts.  With a usable seek index (`index`: a path or a list of paths to try,
+        fasta.fastaIndexPaths; written by fasta.writeFastaIndex) the rank copies just those bytes from the mapped file;
+        without one it parses the whole file natively.  `self.shard_index` = the index that was used, or None.
+        Returns (names of ALL records, (cand_begin, cand_end)): scan() on this batch numbers candidates from 0 = cand_begin."""
         n, total, c0, c1 = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
         flags = _ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0
-        self._check(self._lib.frisk_fasta_load_shard(self._ctx, os.fsencode(path), int(w), int(inc), flags, int(rank), int(world),
-                                                     C.byref(n), C.byref(total), C.byref(c0), C.byref(c1)))
+        self.shard_index = None
+        for cand in ([index] if isinstance(index, (str, bytes, os.PathLike)) else list(index or [])):
+            if not os.path.exists(cand):
+                continue
+            rc = self._lib.frisk_fasta_load_shard_indexed(self._ctx, os.fsencode(path), os.fsencode(cand), int(w), int(inc), flags,
+                                                          int(rank), int(world), C.byref(n), C.byref(total), C.byref(c0), C.byref(c1))
+            if rc == _ffi.E_INDEX:
+                continue                # (not this file's index, or a file the byte arithmetic cannot address: parse instead)
+            self._check(rc)
+            self.shard_index = os.fspath(cand)
+            break
+        if self.shard_index is None:
+            self._check(self._lib.frisk_fasta_load_shard(self._ctx, os.fsencode(path), int(w), int(inc), flags, int(rank), int(world),
+                                                         C.byref(n), C.byref(total), C.byref(c0), C.byref(c1)))
         self.n_seq = int(n.value)
         self.seq_lens = [int(self._lib.frisk_seq_len(self._ctx, i)) for i in range(self.n_seq)]
         names = [self._lib.frisk_seq_name(self._ctx, i).decode("ascii", "replace") for i in range(self.n_seq)]

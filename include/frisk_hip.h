@@ -35,7 +35,8 @@ enum {
     FRISK_E_HIP = -2,         /* a HIP runtime call failed (no device, out of memory, launch failure)  */
     FRISK_E_STATE = -3,       /* call order violated (e.g. scan before a profile is finalised)         */
     FRISK_E_CAP = -4,         /* caller buffer too small; the needed size is reported                  */
-    FRISK_E_ZERO_WEIGHT = -5  /* reserved: ZeroDivisionError cases are reported per row (FRISK_ROW_ZERO_WEIGHT)  */
+    FRISK_E_ZERO_WEIGHT = -5, /* reserved: ZeroDivisionError cases are reported per row (FRISK_ROW_ZERO_WEIGHT)  */
+    FRISK_E_INDEX = -6        /* no usable seek index for this FASTA file: the caller parses it instead  */
 };
 
 /* frisk_scan flags */
@@ -109,6 +110,25 @@ int frisk_fasta_digest(const char* path, int32_t* n_seq, int64_t* total_len, uin
  * seq_index / frisk_seq_name / frisk_seq_len / frisk_seq_count refer to the records of the FASTA, as on one GPU. */
 int frisk_fasta_load_shard(frisk_ctx* ctx, const char* path, int32_t w, int32_t inc, uint32_t flags, int32_t rank,
                            int32_t world, int32_t* n_seq, int64_t* total_len, int64_t* cand_begin, int64_t* cand_end);
+/* The same without parsing the file: a seek index (frisk_amd/csrc/fasta_index.h: one `samtools faidx` line per record behind a
+ * stamp line with the FASTA's size and modification time; a foreign <fasta>.fai that is not older than the file is accepted
+ * too) tells the rank where the bases of ITS tiles are, and it copies those bytes from the mapped file - 1/world of the
+ * file + halos instead of all of it.  The index is checked against the file where it is used (a header line that gives the
+ * record's name ends right before its first base, its last base ends a line).  FRISK_E_INDEX: no usable index (missing,
+ * made from another version of the file, gzip, a record the byte arithmetic cannot address) - call frisk_fasta_load_shard.
+ * The reference reads every record of the file on every run (iterFasta, L139-164). */
+int frisk_fasta_load_shard_indexed(frisk_ctx* ctx, const char* path, const char* index_path, int32_t w, int32_t inc,
+                                   uint32_t flags, int32_t rank, int32_t world, int32_t* n_seq, int64_t* total_len,
+                                   int64_t* cand_begin, int64_t* cand_end);
+/* Host-only: write the seek index of `fasta_path` to `index_path` (one pass over the mapped file).  FRISK_E_INDEX when the
+ * file is not regular - text before the first header, blank lines or surrounding blanks inside a record, lines of different
+ * length before a record's last, gzip - with the reason in `why` (nullable). */
+int frisk_fasta_index_build(const char* fasta_path, const char* index_path, int32_t* n_seq, char* why, int32_t why_cap);
+/* Host-only test / extraction utility: bases [pos0, pos0 + n) of record seq_index through the index (seq_index < 0: the number
+ * of records alone; n = 0: name and length alone).  Any output pointer may be NULL. */
+int frisk_fasta_index_read(const char* fasta_path, const char* index_path, int32_t seq_index, int64_t pos0, int64_t n,
+                           uint8_t* out, int32_t* n_seq, int64_t* seq_len, char* name, int32_t name_cap, char* why,
+                           int32_t why_cap);
 int32_t frisk_seq_count(const frisk_ctx* ctx);
 const char* frisk_seq_name(const frisk_ctx* ctx, int32_t seq_index);   /* "" for batches not loaded from FASTA */
 int64_t frisk_seq_len(const frisk_ctx* ctx, int32_t seq_index);

@@ -31,13 +31,23 @@ class FakeEngine:
         self.load(seqs)
         return names
 
-    def load_fasta_shard(self, path, w, inc, rank, world, scaffolds_all=False):
-        """The tiles of one rank (frisk_amd.distributed.plan_tiles is the specification of frisk_fasta_load_shard)."""
+    def load_fasta_shard(self, path, w, inc, rank, world, scaffolds_all=False, index=None):
+        """The tiles of one rank (frisk_amd.distributed.plan_tiles is the specification of frisk_fasta_load_shard).  With a seek
+        index the tiles' bytes come through the library's host-only index reader (what frisk_fasta_load_shard_indexed copies)."""
         from frisk_amd.distributed import plan_tiles
-        from frisk_amd.fasta import readFasta
-        names, seqs = readFasta(path)
-        (c0, c1), tiles = plan_tiles([len(s) for s in seqs], w, inc, scaffolds_all, self.kmax, rank, world)
-        self.load([seqs[t["scaf"]][t["base0"]:t["end"]] for t in tiles])
+        from frisk_amd.fasta import readFasta, readFastaIndexed
+        self.shard_index = None
+        if index is not None:
+            n = readFastaIndexed(path, index)
+            heads = [readFastaIndexed(path, index, i)[:2] for i in range(n)]
+            names, lens = [h[0] for h in heads], [h[1] for h in heads]
+            (c0, c1), tiles = plan_tiles(lens, w, inc, scaffolds_all, self.kmax, rank, world)
+            self.load([readFastaIndexed(path, index, t["scaf"], t["base0"], t["end"] - t["base0"])[2] for t in tiles])
+            self.shard_index = index
+        else:
+            names, seqs = readFasta(path)
+            (c0, c1), tiles = plan_tiles([len(s) for s in seqs], w, inc, scaffolds_all, self.kmax, rank, world)
+            self.load([seqs[t["scaf"]][t["base0"]:t["end"]] for t in tiles])
         self.tiles, self.tile_geom = tiles, (w, inc, scaffolds_all)
         return names, (c0, c1)
 

@@ -33,8 +33,16 @@ def _run(rank, world, port, mode, out_path):
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     if mode == "files":         # the CLI's mode: replicated data from FASTA files, host != query
         eng = FakeEngine(1, 4)
+        index = query_index = None
+        if world > 1:           # the two ranks read their tiles through seek indices (written once, here by rank 0's process id-free name)
+            from frisk_amd.fasta import writeFastaIndex
+            index, query_index = out_path + ".host.fai", out_path + ".query.fai"
+            if rank == 0:
+                assert writeFastaIndex(os.path.join(INPUTS, "host.fa"), index) and writeFastaIndex(os.path.join(INPUTS, "query.fa"), query_index)
+            dist.barrier()
         rows = run_sharded_files(eng, os.path.join(INPUTS, "host.fa"), 400, 150, rip=True, scaffolds_all=True,
-                                 query_path=os.path.join(INPUTS, "query.fa"))
+                                 query_path=os.path.join(INPUTS, "query.fa"), index=index, query_index=query_index)
+        assert (eng.shard_index is not None) == (world > 1)
     else:
         recs, kw = _job(mode)
         eng = FakeEngine(kw["kmin"], kw["kmax"])

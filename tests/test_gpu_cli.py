@@ -147,6 +147,56 @@ def test_cli_sharded_cache_semantics(tmp_path, monkeypatch):
             dist.destroy_process_group()
 
 
+def test_cli_sharded_seek_index_life_cycle(tmp_path, monkeypatch, caplog):
+    """A sharded job that had to parse the FASTA leaves a seek index beside the other caches (rank 0, background thread); the next
+    one reads its tiles through it - same table; --recalc ignores and rewrites it; an index made from another version of the file
+    is not used."""
+    import logging
+    import torch.distributed as dist
+    from frisk_amd.cli import main
+    c = Case("markov_k6")
+    fasta = tmp_path / "genome.fa"
+    fasta.write_bytes(open(c.host, "rb").read())
+    base = ["-H", str(fasta), "-k", "6", "-w", "400", "-i", "150", "--RIP", "--exitAfter", "WindowKLD", "--recalcWin"]
+    assert main(base + ["-t", str(tmp_path / "P")]) == 0
+    plain = open(tmp_path / "P" / "raw_window_scores.bed").read()
+    assert not os.path.exists(tmp_path / "P" / "genome.fa.frisk.fai")            # (one rank: nothing to shard, no index)
+    for k, v in (("FRISK_FORCE_SHARDED", "1"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"),
+                 ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29647")):
+        monkeypatch.setenv(k, v)
+    S = tmp_path / "S"
+    idx = S / "genome.fa.frisk.fai"
+    try:
+        with caplog.at_level(logging.INFO):
+            assert main(base + ["-t", str(S)]) == 0
+        assert "through the index" not in caplog.text and os.path.isfile(idx)
+        assert open(S / "raw_window_scores.bed").read() == plain
+        stamp = open(idx).readline()
+        caplog.clear()
+        os.remove(S / c.doc["genome_pickle_basename"])                          # (so that phase A runs, and loads, again)
+        with caplog.at_level(logging.INFO):
+            assert main(base + ["-t", str(S)]) == 0
+        assert "through the index %s" % idx in caplog.text
+        assert open(S / "raw_window_scores.bed").read() == plain
+        caplog.clear()
+        t_idx = os.stat(idx).st_mtime_ns
+        with caplog.at_level(logging.INFO):
+            assert main(base + ["-t", str(S), "--recalc"]) == 0                   # recompute: parse, and write the index again
+        assert "through the index" not in caplog.text and os.stat(idx).st_mtime_ns > t_idx
+        # the FASTA changes: the old index is refused (stamp), the job parses and replaces it
+        data = fasta.read_bytes()
+        fasta.write_bytes(data[:40] + data[40:].replace(b"A", b"C", 7))
+        os.remove(S / c.doc["genome_pickle_basename"])
+        caplog.clear()
+        with caplog.at_level(logging.INFO):
+            assert main(base + ["-t", str(S)]) == 0
+        assert "through the index" not in caplog.text and open(idx).readline() != stamp
+        assert open(S / "raw_window_scores.bed").read() != plain
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def test_cli_zero_weight_writes_the_rows_before_the_failure(tmp_path, capsys):
     """The reference writes and prints each row before scoring the next (L1487-1494): when a window dies with
     ZeroDivisionError (L437) the table already holds every row before it."""

@@ -119,7 +119,10 @@ def test_random_cases_up_to_k10(block):
 @pytest.mark.parametrize("block", range(3))
 def test_random_tile_sharding_equals_one_gpu(tmp_path, block):
     """frisk_fasta_load_shard with random geometry, word sizes, scaffold make-up and world size: the ranks of the job played one
-    after the other give the one-GPU raw profile (summed) and the one-GPU rows (concatenated) bit for bit."""
+    after the other give the one-GPU raw profile (summed) and the one-GPU rows (concatenated) bit for bit.  Every other rank
+    reads its tiles through the seek index (frisk_fasta_load_shard_indexed) instead of parsing the file: the same resident
+    words, the same profile share, the same rows."""
+    from frisk_amd.fasta import writeFastaIndex
     rng = np.random.default_rng(4400 + block)
     for case_no in range(4):
         kmax = int(rng.choice([4, 6, 7, 8, 8]))
@@ -141,9 +144,14 @@ def test_random_tile_sharding_equals_one_gpu(tmp_path, block):
                             s[a:a + ln] = ord("N")
                         else:
                             s[a:a + ln] |= 0x20
-                fh.write(b">scaf%d\n" % i)
+                fh.write(b">scaf%d some words\n" % i)
+                eol = b"\r\n" if (case_no + i) % 3 == 0 else b"\n"
                 for o in range(0, n, 61):
-                    fh.write(s[o:o + 61].tobytes() + b"\n")
+                    fh.write(s[o:o + 61].tobytes() + eol)
+                if i % 2:
+                    fh.write(b"\n")                 # (a blank line between records)
+        idx = tmp_path / ("g%d.fa.frisk.fai" % case_no)
+        assert writeFastaIndex(str(fa), str(idx)) is not None
         tag = "block %d case %d: k=%d..%d w=%d i=%d all=%s world=%d" % (block, case_no, kmin, kmax, w, inc, scaffolds_all, world)
         rip = kmin <= 2 <= kmax
         with Engine(kmin, kmax) as e:
@@ -152,12 +160,18 @@ def test_random_tile_sharding_equals_one_gpu(tmp_path, block):
             full = e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
             raws, parts = [], []
             for rank in range(world):
-                _, (c0, c1) = e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all)
+                names_p, (c0, c1) = e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all, index=str(idx) if rank & 1 else None)
+                assert (e.shard_index is not None) == bool(rank & 1), tag
                 e.profile_reset(); e.profile_add()
                 raws.append(e.profile_raw())
+                if rank in (0, world - 1):          # both loaders leave the same words on the device
+                    packed = [x.copy() for x in e.export_packed()]
+                    names_i, cc = e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all, index=None if rank & 1 else [str(idx)])
+                    assert names_i == names_p and cc == (c0, c1) and (e.shard_index is None) == bool(rank & 1), tag
+                    assert all(np.array_equal(x, y) for x, y in zip(packed, e.export_packed())), tag
             assert np.array_equal(np.sum(raws, axis=0), whole_raw), tag
             for rank in range(world):
-                e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all)
+                e.load_fasta_shard(str(fa), w, inc, rank, world, scaffolds_all, index=None if rank & 1 else str(idx))
                 e.profile_set_raw(whole_raw); e.profile_finalize()
                 parts.append(e.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all, chunks=bool(rank & 1)))
             for f in ("seq_index", "start", "stop", "status", "kld", "gc") + (("pi", "si", "cri") if rip else ()):

@@ -1,6 +1,6 @@
 """The N > 1 product path on REAL kernels: two ranks on the one GPU of the test box (gloo for the exchange - RCCL refuses two ranks on
 one device), each with its own Engine, run `frisk_amd.distributed.run_sharded_files`: window tiles + halo from the FASTA file
-(frisk_fasta_load_shard), the raw profiles summed by the all-reduce, every rank scanning its candidate range with the chunked /
+(frisk_fasta_load_shard_indexed: each rank copies the bytes of its tiles from the mapped file), the raw profiles summed by the all-reduce, every rank scanning its candidate range with the chunked /
 sliding kernels, rows gathered on rank 0 as tensors.  Rows and profile must equal the one-rank run bit for bit."""
 import os
 import sys
@@ -31,14 +31,15 @@ def _write_fasta(path):
                 fh.write(s[o:o + 80] + b"\n")
 
 
-def _run(rank, world, port, fasta, out_path):
+def _run(rank, world, port, fasta, out_path, index=None):
     import torch.distributed as dist
     from frisk_amd.distributed import run_sharded_files
     from frisk_amd.engine import Engine
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     with Engine(GEOM["kmin"], GEOM["kmax"], device=0) as eng:
-        rows = run_sharded_files(eng, fasta, GEOM["w"], GEOM["inc"], rip=True, scaffolds_all=True)
+        rows = run_sharded_files(eng, fasta, GEOM["w"], GEOM["inc"], rip=True, scaffolds_all=True, index=index)
+        assert (eng.shard_index is not None) == (index is not None)
         sym, tl, ex, nn = eng.profile_get()
         resident = eng.padded_len
     if rank == 0:
@@ -54,7 +55,10 @@ def test_two_real_ranks_equal_one(tmp_path):
     single, double = str(tmp_path / "single.npy"), str(tmp_path / "double.npy")
     port = 29700 + (os.getpid() % 2000)
     mp.spawn(_run, args=(1, port, fasta, single), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, port + 1, fasta, double), nprocs=2, join=True)
+    # (the two ranks read their tiles through the seek index, the single rank parses the file)
+    from frisk_amd.fasta import writeFastaIndex
+    assert writeFastaIndex(fasta, fasta + ".frisk.fai") == 6
+    mp.spawn(_run, args=(2, port + 1, fasta, double, fasta + ".frisk.fai"), nprocs=2, join=True)
     a = np.load(single, allow_pickle=True)
     b = np.load(double, allow_pickle=True)
     assert len(a[0]) > 1500
