@@ -123,6 +123,18 @@ def write_table(path, table, echo=True):
     printed.  Floats as Python 2's str() prints them (12 significant digits) unless FRISK_FLOAT_REPR=py3.
     The text comes from the library's native formatter in one piece (ScoreTable.text): no per-row Python."""
     fmt = None if _fmt() is pp.py2_str else _fmt()
+    raw = getattr(sys.stdout, "buffer", None) if echo else None
+    if fmt is None and (raw is not None or not echo):
+        # the formatter's bytes go to the file and to stdout as they are (no decode / encode of a few hundred megabytes)
+        body = table.text_bytes()
+        with open(path, "wb") as fh:
+            fh.write(("\t".join(table.columns) + "\n").encode("utf-8"))
+            fh.write(body)
+        if echo:
+            sys.stdout.flush()
+            raw.write(body)
+            raw.flush()
+        return
     body = table.text(fmt)
     with open(path, "w") as fh:
         fh.write("\t".join(table.columns) + "\n")
@@ -143,14 +155,16 @@ def _load_window_cache(path, rip):
 
 
 def _dump_window_cache(path, table):
-    """As the reference: pickle.dump(allWindows DataFrame) (L1501) - so that a reference run, or any tool that reads
-    *_KLD_window_*.p, can load it.  Without pandas: the {columns, rows} form."""
+    """As the reference: pickle.dump(allWindows DataFrame) (L1501) with the interpreter's default protocol - so that a reference
+    run, or any tool that reads *_KLD_window_*.p, can load it.  (Protocol 2 was used here until round 3: under Python 3 it sends
+    every numeric column through a latin-1 text detour - 0.5 s per 3 M rows against 0.15 - and no Python 2 pandas reads a frame
+    pickled by today's pandas anyway.)  Without pandas: the {columns, rows} form."""
     try:
         obj = table.to_frame()
     except ImportError:
         obj = {"columns": table.columns, "rows": table.rows()}
     with open(path, "wb") as fh:
-        pickle.dump(obj, fh, protocol=2)
+        pickle.dump(obj, fh)
 
 
 def main(argv=None):
@@ -305,15 +319,31 @@ def _main(argv=None):
             except ZeroDivisionError as err:
                 zero, table = err, getattr(err, "table", None)
             clock.lap("phase B (scan)")
+            dumper, dump_err = None, []
             if rank == 0 and table is not None:
+                if zero is None:
+                    # the window cache (L1501) is pickled while the table text is formatted and written (native code, outside the
+                    # interpreter lock): two files of the same rows, neither reads the other
+                    import threading
+
+                    def _dump():
+                        try:
+                            _dump_window_cache(windowsPickle, table)
+                        except BaseException as err:        # noqa: B902 - re-raised on the main thread below
+                            dump_err.append(err)
+                    dumper = threading.Thread(target=_dump, name="frisk-window-cache")
+                    dumper.start()
                 # the reference writes and prints row by row (L1487-1494): what it had written before dying is written here too
-                write_table(os.path.join(args.tempDir, args.outfile), table)
-                clock.lap("score table text")
+                try:
+                    write_table(os.path.join(args.tempDir, args.outfile), table)
+                finally:
+                    if dumper is not None:
+                        dumper.join()
+                clock.lap("score table text + window pickle")
             if zero is not None:
                 raise zero
-            if rank == 0:
-                _dump_window_cache(windowsPickle, table)
-                clock.lap("window pickle")
+            if dump_err:
+                raise dump_err[0]
     finally:
         for th in index_writers:
             th.join()

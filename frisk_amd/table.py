@@ -104,6 +104,13 @@ class ScoreTable:
             return ""
         if fmt is not None:
             return "".join("\t".join(fmt(v) for v in self.row(r)) + "\n" for r in range(n))
+        return self.text_bytes().decode("utf-8", "replace")
+
+    def text_bytes(self):
+        """The table body as the native formatter's bytes (UTF-8; Python 2's str() for floats)."""
+        n = len(self)
+        if n == 0:
+            return b""
         lib = _ffi.lib()
         names = (C.c_char_p * max(len(self.names), 1))(*[s.encode("utf-8", "replace") for s in self.names])
         p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None      # noqa: E731
@@ -113,6 +120,6 @@ class ScoreTable:
         if not buf:
             raise MemoryError("frisk_format_rows failed")
         try:
-            return C.string_at(buf, out_len.value).decode("utf-8", "replace")
+            return C.string_at(buf, out_len.value)
         finally:
             lib.frisk_free(C.c_void_p(buf))

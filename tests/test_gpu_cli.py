@@ -166,6 +166,7 @@ def test_cli_sharded_seek_index_life_cycle(tmp_path, monkeypatch, caplog):
         monkeypatch.setenv(k, v)
     S = tmp_path / "S"
     idx = S / "genome.fa.frisk.fai"
+    genome_pickle = S / c.doc["genome_pickle_basename"].replace(os.path.basename(c.host), "genome.fa")
     try:
         with caplog.at_level(logging.INFO):
             assert main(base + ["-t", str(S)]) == 0
@@ -173,7 +174,7 @@ def test_cli_sharded_seek_index_life_cycle(tmp_path, monkeypatch, caplog):
         assert open(S / "raw_window_scores.bed").read() == plain
         stamp = open(idx).readline()
         caplog.clear()
-        os.remove(S / c.doc["genome_pickle_basename"])                          # (so that phase A runs, and loads, again)
+        os.remove(genome_pickle)                          # (so that phase A runs, and loads, again)
         with caplog.at_level(logging.INFO):
             assert main(base + ["-t", str(S)]) == 0
         assert "through the index %s" % idx in caplog.text
@@ -186,7 +187,7 @@ def test_cli_sharded_seek_index_life_cycle(tmp_path, monkeypatch, caplog):
         # the FASTA changes: the old index is refused (stamp), the job parses and replaces it
         data = fasta.read_bytes()
         fasta.write_bytes(data[:40] + data[40:].replace(b"A", b"C", 7))
-        os.remove(S / c.doc["genome_pickle_basename"])
+        os.remove(genome_pickle)
         caplog.clear()
         with caplog.at_level(logging.INFO):
             assert main(base + ["-t", str(S)]) == 0
