@@ -230,7 +230,8 @@ def shape_block(eng, lens, kw, step, fence, steps, label):
             "value": rows / dt, "unit": "windows/s (emitted rows, as `value`)", "candidate_windows_per_s": n / dt,
             "ms_per_step": dt * 1e3, "scan_kernel_ms": scan_ms, "rows": rows, "candidate_windows": n,
             "share_of_candidates_kept": rows / max(n, 1),
-            "scan_counter_width": {"bulk_bits": width, "windows_handed_to_8bit": h8, "windows_handed_to_16bit": h16},
+            "scan_counter_width": {"bulk_bits": width, "side_table_for_period4_maxmers": eng.scan_side(), "windows_handed_to_8bit": h8,
+                                   "windows_handed_to_16bit": h16},
             "cold_first_step_ms": cold_ms, "cold_first_scan_kernel_ms": cold_scan_ms,
             "max_kld": float(np.nanmax(res.kld[res.kept])) if rows else None}
 
@@ -417,6 +418,7 @@ def main(argv=None):
         b_alg = 0.25 * total_bases + 40.0 * rows + 8.0 * sum(4 ** x for x in range(KMIN, KMAX + 1))
         achieved = b_alg / (scan_avg * 1e-3) / 1e9
         width, handed8, handed16, row_segments = eng.scan_stat()
+        side_table = eng.scan_side()
         traffic, binding, pmc_src = None, None, None
         # HBM traffic and issue counters: rocprofv3 --pmc passes of THIS workload, collected offline (separate runs, never
         # combined with tracing) and committed; valid only for the same shard and the same kernel
@@ -447,7 +449,8 @@ def main(argv=None):
             "windowed_gbases_per_s": rows_all * W / (elapsed / opts.steps) / 1e9,      # rows x w: bases looked at, overlap counted
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
             "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
-            "scan_counter_width": {"bulk_bits": width, "windows_handed_to_8bit": handed8, "windows_handed_to_16bit": handed16},
+            "scan_counter_width": {"bulk_bits": width, "side_table_for_period4_maxmers": side_table, "windows_handed_to_8bit": handed8,
+                                   "windows_handed_to_16bit": handed16},
             "scan_row_segments": row_segments,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRISK_HIP_LIB") or os.path.join(_HERE, "libfrisk_hip.so")   # override: kernel experiments
 
 OK, E_ARG, E_HIP, E_STATE, E_CAP, E_ZERO_WEIGHT, E_INDEX = 0, -1, -2, -3, -4, -5, -6
-SCAN_RIP, SCAN_SCAFFOLDS_ALL, SCAN_CHUNKS, SCAN_BITS4 = 1, 2, 256, 512
+SCAN_RIP, SCAN_SCAFFOLDS_ALL, SCAN_CHUNKS, SCAN_BITS4, SCAN_SIDE4 = 1, 2, 256, 512, 1024
 ROW_KEPT, ROW_ZERO_WEIGHT, ROW_JUMPBACK, ROW_NO_MAXMER = 1, 2, 4, 8
 
 # every symbol include/frisk_hip.h declares: (name, restype, argtypes)

@@ -29,6 +29,9 @@
 #ifndef FRISK_K7_WPS
 #define FRISK_K7_WPS 4              // waves per SIMD (= 256-thread workgroups per CU) of the K = 6, 7 narrow-counter kernels
 #endif
+#ifndef FRISK_SIDE_SHARE
+#define FRISK_SIDE_SHARE 0.08       // 4-bit bulk takes the side-table form when the plain form would hand on more than this share of the sample
+#endif
 #ifndef FRISK_K8_WIDTH
 #define FRISK_K8_WIDTH 0            // order-8 counters of the default K = 8 path (scan8_kernel.h): 0 = adaptive 4/8 bits, 4, 8, 16 = off
 #endif
@@ -83,7 +86,7 @@ struct frisk_ctx {
             int32_t kind;               // as ScafDesc::kind
             int64_t own0, own1;         // [own0, own1): scaffold positions whose k-mers THIS rank counts in phase A
         };
-        int width_hint = 0, hint_w = 0, hint_inc = 0;   // counter width the last sampled scan of this batch chose (0: none yet)
+        int width_hint = 0, hint_w = 0, hint_inc = 0, hint_side = 0;   // counter width the last sampled scan of this batch chose (0: none yet)
         bool tiled = false;
         std::vector<Tile> tiles;
         int32_t tile_w = 0, tile_inc = 0;
@@ -117,7 +120,8 @@ struct frisk_ctx {
     DevBuf<int64_t> d_ovf_list, d_ovf_list2;   // windows handed from 4-bit to 8-bit counters, and from there to the 16-bit form
     DevBuf<double> d_ig_ring;                  // scan8_kernel: per-workgroup ring of genome-side values by position (80 KB each at 20 positions per lane)
     DevBuf<unsigned int> d_ovf_count;          // per row segment 32 counters: [0], [1] the lists' lengths, [8..15] the bulk launch's chunk queues, [16] the 8-bit launch's
-    int64_t scan_stat[4] = {0, 0, 0, 0};       // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16, row segments
+    int64_t scan_stat[5] = {0, 0, 0, 0, 0};    // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16, row segments,
+                                               // 1 = the bulk launch had the side table for period-4 max-mers beside its 4-bit counters
     DevBuf<uint32_t> d_big;      // 32-bit tables of the long-window path (scan_big_kernel.h), one slice per workgroup
     DevBuf<int64_t> d_meta;          // {totalLen, exMax, nnTotal} of the finalised profile, on the device
     int64_t* h_meta = nullptr;       // page-locked mirror, valid after the stream has been synchronised
@@ -303,25 +307,31 @@ hipError_t launch_scan(const ScanParams& P, int grid, size_t lds, hipStream_t st
     return hipGetLastError();
 }
 
-template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG, int ROLE = 0>
+template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG, int ROLE = 0, bool SIDE = false>
 hipError_t launch_scan8(const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st) {
     constexpr int wg_per_cu = WPS * 256 / NT;
-    static_assert(Lds8<KMAX, BITS, LOGN, NT>::total * wg_per_cu <= 160 * 1024, "the workgroups meant to share a CU must fit its LDS");
+    static_assert(Lds8<KMAX, BITS, LOGN, NT, SIDE>::granules * 1280 * wg_per_cu <= 160 * 1024, "the workgroups meant to share a CU must fit its LDS (allocated in pieces of 1280 bytes)");
     int grid = int(std::max<int64_t>(1, std::min<int64_t>(work_items, int64_t(num_cu) * wg_per_cu)));
     if (grid >= 8) grid &= ~7;
-    scan8_kernel<KMAX, NT, ITS, BITS, LOGN, WPS, DEBUG, ROLE><<<grid, NT, 0, st>>>(P);      // LDS is static (Lds8)
+    scan8_kernel<KMAX, NT, ITS, BITS, LOGN, WPS, DEBUG, ROLE, SIDE><<<grid, NT, 0, st>>>(P);      // LDS is static (Lds8)
     return hipGetLastError();
 }
 
 // one launch of the narrow-counter K = 8 kernel: counter width, window class (<= 2048 / <= 5120 bases), debug dump
+// (side: 4-bit counters with the side table for the period-4 max-mers - launches whose windows slide only)
 hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st,
-                         bool sample = false) {
+                         bool sample = false, bool side = false) {
     const bool slides = P.slide_pp > 0 && P.in_list == nullptr;        // (else: the instantiation without the ring, ROLE bit 1)
-    if (sample) {           // the 1/16 sample of the adaptive width: 4-bit counters, its own name in kernel statistics
-        if (small_w) return slides ? launch_scan8<8, 256, 8, 4, 64, 3, false, 1>(P, num_cu, work_items, st)
+    if (sample) {           // the 1/16 sample of the adaptive width: 4-bit counters, its own name in kernel statistics; where the
+                            // windows slide it runs the side-table form and counts what the plain form would have handed on as well
+        if (small_w) return slides ? launch_scan8<8, 256, 8, 4, 64, 3, false, 1, true>(P, num_cu, work_items, st)
                                    : launch_scan8<8, 256, 8, 4, 64, 3, false, 3>(P, num_cu, work_items, st);
-        return slides ? launch_scan8<8, 256, 20, 4, 64, 3, false, 1>(P, num_cu, work_items, st)
+        return slides ? launch_scan8<8, 256, 20, 4, 64, 3, false, 1, true>(P, num_cu, work_items, st)
                       : launch_scan8<8, 256, 20, 4, 64, 3, false, 3>(P, num_cu, work_items, st);
+    }
+    if (side && slides && bits == 4 && kmax == 8 && !debug) {
+        if (small_w) return launch_scan8<8, 256, 8, 4, 64, 3, false, 0, true>(P, num_cu, work_items, st);
+        return launch_scan8<8, 256, 20, 4, 64, 3, false, 0, true>(P, num_cu, work_items, st);
     }
 #define FRISK_L7(K_, ITS_, DBG_) return launch_scan8<K_, 256, ITS_, 8, 64, FRISK_K7_WPS, DBG_>(P, num_cu, work_items, st)
     if (kmax == 7) {        // K = 6, 7: the 8-bit table is 16 / 4 KiB - registers, not LDS, bound the workgroups per CU
@@ -1222,7 +1232,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
     P.stamps = nullptr;
     P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
     P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr; P.queue_n = 1; P.slide_pp = 0; P.ig_ring = nullptr;
-    c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0; c->scan_stat[3] = 1;
+    c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0; c->scan_stat[3] = 1; c->scan_stat[4] = 0;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
     HIPC(c, d_stamps.reserve(4 * 16 * 12));
@@ -1349,12 +1359,14 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         // chunks dealt by counters (scan8_kernel.h) where a chunk is long enough to pay for the exchange: a short scan keeps the static deal
         const bool dealt = chunk8 >= 4;
         int bulk = (width == 4 && narrow8) ? 4 : 8;
+        bool side = false;              // 4-bit bulk with the side table (scan8_kernel.h, SIDE)
+        const bool side_ok = narrow8 && !debug && P.slide_pp > 0;
         int sel_mode = 0;
         frisk_ctx::Batch& RB = c->b();
         const bool hinted = RB.width_hint != 0 && RB.hint_w == w && RB.hint_inc == inc;
         if (narrow7) { /* 8-bit bulk, no sample */ }
-        else if ((flags & FRISK_SCAN_BITS4) && narrow8) bulk = 4;
-        else if (width == 0 && !debug && hinted) bulk = RB.width_hint;      // same batch, same geometry: the earlier sample still holds
+        else if ((flags & (FRISK_SCAN_BITS4 | FRISK_SCAN_SIDE4)) && narrow8) { bulk = 4; side = (flags & FRISK_SCAN_SIDE4) && side_ok; }
+        else if (width == 0 && !debug && hinted) { bulk = RB.width_hint; side = RB.hint_side && side_ok; }   // same batch, same geometry: the earlier sample still holds
         else if (width == 0 && !debug && nchunks >= 64 * P.sel_mod) {
             ScanParams S = P;                   // the sample
             S.chunk = int32_t(chunk8);
@@ -1362,15 +1374,21 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             if (dealt) { S.queue = c->d_ovf_count.p + 8; S.queue_n = 8; }
             const int64_t nsample = (nchunks + S.sel_mod - 1) / S.sel_mod;
             HIPC(c, launch_narrow(c->kmax, 4, small_w, false, S, c->num_cu, nsample, c->stream, true));
-            unsigned int handed = 0;
-            HIPC(c, hipMemcpyAsync(&handed, c->d_ovf_count.p, sizeof(handed), hipMemcpyDeviceToHost, c->stream));
+            unsigned int sampled[4] = {0, 0, 0, 0};     // handed on; -; (side-table form) scored, but a plain 4-bit counter would have wrapped; scored
+            HIPC(c, hipMemcpyAsync(sampled, c->d_ovf_count.p, sizeof(sampled), hipMemcpyDeviceToHost, c->stream));
             HIPC(c, hipStreamSynchronize(c->stream));
+            const unsigned int handed = sampled[0];
             // 4-bit pays while fewer than about three windows in ten have to be redone (round 3, bench shard with simple repeats at
             // 0.05 / 0.1 / 0.2 / 0.3 per kb = 10 / 20 / 37 / 51 % of the scored windows handed on: 4-bit bulk 7.27 / 7.96 / 8.97 /
             // 9.98 ms, 8-bit bulk 8.51 / 8.57 / 8.71 / 8.78 ms - tools/exp/width_sweep.sh)
             bulk = (double(handed) <= 0.3 * double(nsample * chunk8)) ? 4 : 8;
+            // ... and the side table pays when the plain form would hand on more than FRISK_SIDE_SHARE of the windows that are scored
+            // (measured on the bench shard: it costs a scored window 1.6 ns - ten instructions per position -, a window handed on
+            // 18 ns - a skeleton and a second scoring without sliding: tools/exp/side_rate.py)
+            side = bulk == 4 && side_ok && double(handed + sampled[2]) > FRISK_SIDE_SHARE * double(handed + sampled[3]);
+            if (const char* ev = tune_env("FRISK_SIDE")) side = side_ok && bulk == 4 && std::atoi(ev) != 0;
             sel_mode = 2;
-            RB.width_hint = bulk; RB.hint_w = w; RB.hint_inc = inc;
+            RB.width_hint = bulk; RB.hint_w = w; RB.hint_inc = inc; RB.hint_side = side ? 1 : 0;
             // the sample's own hand-overs now (list 1 -> 8-bit -> list 2 -> 16-bit), so that lists and counters are free for
             // the bulk segments and no later pass touches rows of another segment
             ScanParams H = P;
@@ -1387,6 +1405,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             HIPC(c, hipMemsetAsync(c->d_ovf_count.p, 0, 64 * sizeof(unsigned int), c->stream));
         }
         c->scan_stat[0] = bulk;
+        c->scan_stat[4] = side ? 1 : 0;
         // Rows [r0, r1) of this scan on stream `st`: bulk launch, the two hand-over launches, the rows' scalar tail, and the
         // rows' scalar tail.  Segment `seg` has its own slice of the two lists (from entry r0) and its own 32 counters: [0], [1]
         // the lists' lengths, [8..15] the bulk launch's chunk queues (one per XCD), [16] the 8-bit launch's.
@@ -1410,7 +1429,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             if (dealt) { B.queue = cnt + 8; B.queue_n = 8; }
             const int64_t mchunks = (m + chunk8 - 1) / chunk8;
             const int64_t bulk_chunks = sel_mode == 2 ? mchunks - (mchunks + B.sel_mod - 1) / B.sel_mod : mchunks;
-            HIPC(c, launch_narrow(c->kmax, bulk, small_w, debug, B, c->num_cu, bulk_chunks, st));
+            HIPC(c, launch_narrow(c->kmax, bulk, small_w, debug, B, c->num_cu, bulk_chunks, st, false, side));
             if (bulk == 4) {                        // list 1 (4-bit hand-overs) -> 8-bit -> list 2
                 ScanParams H = R;
                 H.in_list = list1; H.in_count = cnt;
@@ -1566,6 +1585,6 @@ char* frisk_format_rows(int64_t n, const char* const* names, const int32_t* seq_
 }
 void frisk_free(void* p) { std::free(p); }
 
-int64_t frisk_last_scan_stat(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->scan_stat[which] : -1; }
+int64_t frisk_last_scan_stat(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 5) ? c->scan_stat[which] : -1; }
 
 }  // extern "C"

@@ -74,20 +74,24 @@ enum { M8_NPLACED = 1,             // misc slots (0, 2, 4, 5: M_UPA, M_UPG, M_NO
 // LDS carve-up, all compile-time: the kernels declare it as ONE static array, so every table address is a constant that
 // folds into the 16-bit offset field of the ds_ instructions (a dynamic `extern __shared__` base costs one VALU add per
 // address).  The 32 / 64 KiB order-8 table comes LAST: its own offset is then the only large one, and it is an immediate.
-template <int KMAX, int BITS, int LOGN, int NT>
+template <int KMAX, int BITS, int LOGN, int NT, bool SIDE = false>
 struct Lds8 {
     static constexpr uint32_t small = 0;
     static constexpr uint32_t small_bytes = 2736;                                  // orders kmin..KMAX-3 as u16 bins (sized for 1..5)
     static constexpr uint32_t orphans = small + small_bytes;                       // u16[FRISK8_ORPH_CAP]
     static constexpr uint32_t NL = 1u << (2 * (KMAX - 3));                         // entries of the shared prefix tables (level KMAX-3)
     static constexpr uint32_t pre = (orphans + FRISK8_ORPH_CAP * 2 + 15) / 16 * 16;     // Pre8[NL]: the shared prefix sums, 12 bytes each
-    static constexpr uint32_t logtab = pre + NL * 12;                              // {1/c_i, -ln(1/c_i)} x LOGN
+    // SIDE (below): the weights of the prefix sums are 8-byte entries {W, the side count of the (K-3)-mer's 4-mer}, and the side table follows
+    // (8-bit side counters: LDS is handed out in pieces of 1280 bytes on gfx950, three workgroups per CU get 42 of them each = 53 760)
+    static constexpr uint32_t side = pre + NL * (SIDE ? 16 : 12);                  // u8[256]: counts of the period-4 max-mers (SIDE)
+    static constexpr uint32_t logtab = side + (SIDE ? 256 : 0);                    // {1/c_i, -ln(1/c_i)} x LOGN
     // {1/c, c^2 r_K} for c < 16 (second half per window); the 8-bit form has 128 bytes to spare, not 256: 1/c only, the other computed
     static constexpr uint32_t rctab = logtab + uint32_t(LOGN) * 16;
     static constexpr uint32_t misc = rctab + 16 * (BITS == 4 ? 16 : 8);            // counters x2, then one {Sw, Sg, T} per wave
     static constexpr uint32_t t8 = (misc + 2 * FRISK8_SLOTS * 4 + uint32_t(NT / 64) * 3 * 8 + 15) / 16 * 16;
     static constexpr uint32_t t8_bytes = (1u << (2 * KMAX)) * BITS / 8;
     static constexpr uint32_t total = t8 + t8_bytes;
+    static constexpr uint32_t granules = (total + 1279) / 1280;                    // what the hardware allocates
 };
 
 // ln(x), x positive and normal, by table range reduction as scan_kernel.h's log_tab_pos: x = m 2^k, m in [0.5, 1); the top
@@ -130,7 +134,10 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
 // per-kernel statistics then keep the 1/16 sample launches apart from the bulk launches.
 // NT threads, windows of at most NT*ITS bases, BITS per order-8 counter, LOGN: bins of the logarithm table, WPS: waves per SIMD the register allocation must allow (= workgroups per
 // CU * NT / 256).
-template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG, int ROLE = 0>
+// SIDE (K = 8, 4-bit counters): the max-mers of period <= 4 - (x0 x1 x2 x3)(x0 x1 x2 x3): poly-A, (CA)n, (AAAT)n ..., the words that
+// wrap a 4-bit counter in real assemblies - are counted in a side table of 256 16-bit counters instead of the order-K table;
+// see "SIDE" in the kernel body.
+template <int KMAX, int NT, int ITS, int BITS, int LOGN, int WPS, bool DEBUG, int ROLE = 0, bool SIDE = false>
 __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     static_assert(KMAX >= 6 && KMAX <= 8, "highest order 6, 7 or 8");
     constexpr int K = KMAX, LVL = KMAX - 3;              // highest order; level of the shared prefix tables (and of the small tables' top)
@@ -142,7 +149,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     constexpr int NW = NT / 64;
     constexpr int SHW = BITS == 8 ? 2 : 3;               // code >> SHW = dword of the table
     constexpr uint32_t PERM = (32 / BITS) - 1;           // code & PERM = field inside the dword
-    using L = Lds8<KMAX, BITS, LOGN, NT>;
+    static_assert(!SIDE || (KMAX == 8 && BITS == 4 && !DEBUG && NT == 256), "the side table exists for the 4-bit form at K = 8");
+    using L = Lds8<KMAX, BITS, LOGN, NT, SIDE>;
     // the order-K table is cleared whole when that takes no more stores per thread than a lane has positions (measured: 64 KiB
     // for windows of 2000 bases is the one case where every position clearing its own dword is cheaper)
     constexpr bool CLEAR_ALL = L::t8_bytes / 16 / NT <= uint32_t(ITS);
@@ -174,8 +182,37 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     Pre8* pre = reinterpret_cast<Pre8*>(lds + L::pre);
     double* preA = reinterpret_cast<double*>(lds + L::pre);                    // (FRISK8_PRE_SPLIT: NL doubles, then NL words)
     uint32_t* preW = reinterpret_cast<uint32_t*>(lds + L::pre + NL * 8);
-    auto put_pre = [&](uint32_t idx, double A, uint32_t W) __attribute__((always_inline)) {
-        if (FRISK8_PRE_SPLIT) { preA[idx] = A; preW[idx] = W; } else { pre[idx].A = A; pre[idx].W = W; }
+    // SIDE.  A window of a real assembly that holds a max-mer 16+ times nearly always holds a SIMPLE one: a poly-A tail, a
+    // (CA)n or (AAAT)n run.  Such a window wraps a 4-bit counter and had to be redone with 8-bit counters - two workgroups per
+    // CU instead of three - and on repeat-rich sequence that was every other window.  The SIDE form keeps the 4-bit table and
+    // counts the 256 max-mers of period <= 4 - code (y << 8) | y, y = x0 x1 x2 x3 - beside it, in 8-bit counters indexed by y:
+    //   * stage 1 sends a position with such a max-mer to side[y] instead of the table (same for the sliding updates);
+    //   * stage 3: thread t holds the 4-mer t, so side[t] is ITS count - one of the 64 max-mers below its (K-3)-mer 4 t + x0: it
+    //     adds side[t] there (and to the table's grand total), which makes every order <= K-3 right, and stores side[t]
+    //     beside the weight of each of its four (K-3)-mers' prefix sums: the scoring loop's read of W brings it along;
+    //   * stage 4: the only period-4 max-mer below the (K-2)-mer x0..x5 of a position is (x0 x1 x2 x3)^2 - if x4 x5 = x0 x1 -, and
+    //     likewise for its (K-1)-mer (x4 x5 x6 = x0 x1 x2) and the max-mer itself: with t = (code ^ code >> 8) & 0xFF the side
+    //     count joins c_{K-2} if t < 16, c_{K-1} if t < 4, c_K if t = 0 - as the start values of the sums that are there anyway;
+    //   * a count beyond 15 takes the reciprocal and the top order's term the way the 8-bit form computes them (same bits).
+    // Max-mers that are NOT of period <= 4 and occur 16+ times still wrap their counter: grand-total test, hand-over, as before -
+    // and so does a side counter at 256 (the side counts are part of the grand total): a window with a max-mer that occurs 256+ times
+    // is the 16-bit form's whichever form the bulk runs in - a property of the window, so rows do not depend on the launch's shape.
+    uint32_t* side32 = reinterpret_cast<uint32_t*>(lds + L::side);
+    const unsigned char* side8 = lds + L::side;
+    auto put_pre = [&](uint32_t idx, double A, uint32_t W, uint32_t sd = 0u) __attribute__((always_inline)) {
+        if constexpr (SIDE) { preA[idx] = A; reinterpret_cast<uint2*>(preW)[idx] = make_uint2(W, sd); }
+        else if (FRISK8_PRE_SPLIT) { preA[idx] = A; preW[idx] = W; } else { pre[idx].A = A; pre[idx].W = W; }
+    };
+    // (stage 1) one max-mer position more (SIGN = +1) or less (-1): the table's field, or the side counter of a period-4 max-mer
+    auto bump = [&](uint32_t c16, auto sign_c) __attribute__((always_inline)) {
+        constexpr int SIGN = decltype(sign_c)::value;
+        if (SIDE && ((c16 ^ (c16 >> 8)) & 0xFFu) == 0u) {
+            const uint32_t one = 1u << ((c16 & 3u) * 8u);
+            if (SIGN > 0) atomicAdd(&side32[(c16 & 0xFFu) >> 2], one); else atomicSub(&side32[(c16 & 0xFFu) >> 2], one);
+        } else {
+            const uint32_t one = 1u << ((c16 & PERM) * BITS);
+            if (SIGN > 0) atomicAdd(&t8[c16 >> SHW], one); else atomicSub(&t8[c16 >> SHW], one);
+        }
     };
     uint32_t* misc_base = reinterpret_cast<uint32_t*>(lds + L::misc);
     double* scratch = reinterpret_cast<double*>(lds + L::misc + 2 * FRISK8_SLOTS * 4);
@@ -186,6 +223,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     auto clear_t8 = [&]() {
 #pragma unroll
         for (int i = tid0; i < int(L::t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
+        if (SIDE && tid0 < 64) side32[tid0] = 0u;         // (the side table lives and dies with the order-K table)
     };
     auto clear_small = [&]() {
         for (uint32_t i = tid0; i < L::small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
@@ -489,7 +527,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     for (int it = 0; it < ITS; ++it) {
                         const uint32_t bit = 0x80000000u >> it;
                         const uint32_t c16 = code_at(it);
-                        if (fullm & bit) atomicAdd(&t8[c16 >> SHW], 1u << ((c16 & PERM) * BITS));
+                        if (fullm & bit) bump(c16, std::integral_constant<int, 1>{});
                         else if (!few && (shortm & bit)) short_word(c16, (ainv >> (24 - it)) & 0xFFu, n - (j0 + it));
                     }
                 } else {
@@ -499,8 +537,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         const uint32_t bit = 0x80000000u >> it;
                         const uint32_t cs = uint32_t(scode >> (64 - 2 * K - 2 * it)) & (NK - 1u);
                         const uint32_t cn = uint32_t(ecode >> (64 - 2 * K - 2 * it)) & (NK - 1u);
-                        if (sfull & bit) atomicSub(&t8[cs >> SHW], 1u << ((cs & PERM) * BITS));
-                        if (efull & bit) atomicAdd(&t8[cn >> SHW], 1u << ((cn & PERM) * BITS));
+                        if (sfull & bit) bump(cs, std::integral_constant<int, -1>{});
+                        if (efull & bit) bump(cn, std::integral_constant<int, 1>{});
                     }
                     if (!few) {
                         for (int it = 0; it < ITS; ++it)
@@ -654,7 +692,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             uint32_t o7c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};     // the (K-1)-mers again, compacted: n7 of them
             int n7 = 0, n_list = 0;             // n_list: orphans that stayed on the list (all of them without PLACE)
             uint32_t rest_mask = 0;             // ... those beyond the first four, as bits over the list's entries
-            static_assert(L::orphans % 8 == 0 && FRISK8_ORPH_CAP <= 32, "the orphan list: eight-byte aligned, one mask bit per entry");
+            static_assert(L::orphans % 8 == 0 && FRISK8_ORPH_CAP <= 31, "the orphan list: eight-byte aligned, one mask bit per entry (bit 31 of the mask word: SIDE)");
             // (called behind stage 3's barrier: `placed` = the entries that were folded into the table there)
             auto load_orphans = [&](uint32_t placed) {
                 uint32_t todo = (n_orph >= 32 ? 0xFFFFFFFFu : ((1u << n_orph) - 1u)) & ~placed;
@@ -681,7 +719,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             };
             // what a max-mer position reads, all of it addressed by the code alone (so it can be fetched ahead of use):
             // genome-side value, the order-8 counters of its 6-mer / 7-mer / itself, the shared-prefix sums
-            struct Fetched { double Ig, A5; uint32_t W5, c8, w7, roff; uint4 w6; };
+            struct Fetched { double Ig, A5; uint32_t W5, c8, w7, roff, sd; uint4 w6; };       // (sd: SIDE - the side count of the code's 4-mer)
             // (`it`: the lane's position the code belongs to, whose genome-side value waits in the ring - a 1.0 where the position
             //  starts no max-mer: the stand-in it scores has weight 0, any finite number will do;
             //  mode: 0 counts only; 1 the scoring loop of a wave whose lanes all read the ring; 2 ... of a wave with lanes that gather)
@@ -711,7 +749,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     const uint2 x = *reinterpret_cast<const uint2*>(t8b + ((c16 >> 4) << 3));
                     f.w6 = make_uint4(x.x, x.y, 0u, 0u);
                 }
-                if (FRISK8_PRE_SPLIT) {
+                f.sd = 0;
+                if constexpr (SIDE) {
+                    const uint2 ws = *reinterpret_cast<const uint2*>(lds + L::pre + NL * 8 + ((c16 >> 6) << 3));
+                    f.W5 = ws.x; f.sd = ws.y;
+                    f.A5 = *reinterpret_cast<const double*>(lds + L::pre + ((c16 >> 6) << 3));
+                } else if (FRISK8_PRE_SPLIT) {
                     f.W5 = *reinterpret_cast<const uint32_t*>(lds + L::pre + NL * 8 + ((c16 >> 6) << 2));
                     f.A5 = *reinterpret_cast<const double*>(lds + L::pre + ((c16 >> 6) << 3));
                 } else {
@@ -722,7 +765,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 return f;
             };
             // counts of the three top orders of the max-mer c16 as the order-K table holds them: without the orphans
-            auto table_counts = [&](const Fetched& f, uint32_t c16, uint32_t& c8, uint32_t& c7, uint32_t& c6) __attribute__((always_inline)) {
+            // (tper, SIDE: (code ^ code >> 8) & 0xFF of the POSITION's own max-mer - 0xFFFFFFFF: computed here from c16)
+            auto table_counts = [&](const Fetched& f, uint32_t c16, uint32_t& c8, uint32_t& c7, uint32_t& c6, uint32_t tper = 0xFFFFFFFFu) __attribute__((always_inline)) {
                 if (BITS == 8) {
                     c8 = f.c8;
                     c7 = __builtin_amdgcn_sad_u8(f.w7, 0u, 0u);
@@ -735,9 +779,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     // (the dot product's 0x1111 ignores what the shift leaves above them)
                     const uint32_t w7 = uint32_t(((uint64_t(f.w6.y) << 32) | f.w6.x) >> ((c16 & 12u) << 2));
 #endif
-                    c8 = __builtin_amdgcn_ubfe(w7, (c16 & 3u) * 4u, 4u);
-                    c7 = __builtin_amdgcn_udot8(w7, 0x1111u, 0u, false);
-                    c6 = __builtin_amdgcn_udot8(f.w6.x, 0x11111111u, __builtin_amdgcn_udot8(f.w6.y, 0x11111111u, 0u, false), false);
+                    // (SIDE: the period-4 max-mer below the code's (K-2)-mer / (K-1)-mer / the code itself, where there is one)
+                    uint32_t s6 = 0u, s7 = 0u, s8 = 0u;
+                    if constexpr (SIDE) {
+                        const uint32_t t = tper != 0xFFFFFFFFu ? tper : ((c16 ^ (c16 >> 8)) & 0xFFu);
+                        s6 = t < 16u ? f.sd : 0u; s7 = t < 4u ? f.sd : 0u; s8 = t == 0u ? f.sd : 0u;
+                    }
+                    c8 = __builtin_amdgcn_ubfe(w7, (c16 & 3u) * 4u, 4u) + s8;
+                    c7 = __builtin_amdgcn_udot8(w7, 0x1111u, s7, false);
+                    c6 = __builtin_amdgcn_udot8(f.w6.x, 0x11111111u, __builtin_amdgcn_udot8(f.w6.y, 0x11111111u, s6, false), false);
                 }
             };
             // ... and the orphans on top (any number of them: row metadata and the debug dump; stage 4 has its own, unrolled)
@@ -807,11 +857,16 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                                 const uint2 g = *reinterpret_cast<const uint2*>(t8b + q6 * 8u);   // sixteen counters: four (K-1)-mers of four
                                 if (!(e & 0x8000u)) {                    // a (K-1)-mer: a zero counter among its four children
                                     const uint32_t f = ((e & 2u) ? g.y : g.x) >> ((e & 1u) * 16u) & 0xFFFFu;
-                                    const uint32_t z = ~(f | (f >> 1) | (f >> 2) | (f >> 3)) & 0x1111u;
+                                    uint32_t z = ~(f | (f >> 1) | (f >> 2) | (f >> 3)) & 0x1111u;
+                                    // (SIDE: the period-4 child of x0..x6 - the one that ends in x3, if x4 x5 x6 = x0 x1 x2 - has a zero
+                                    //  counter in the table whatever its count: never the fake's place)
+                                    if (SIDE && ((e ^ (e >> 8)) & 0x3Fu) == 0u) z &= ~(1u << (((e >> 6) & 3u) * 4u));
                                     if (z) slot = ((e & 0x3FFFu) << 2) | uint32_t((__ffs(int(z)) - 1) >> 2);
                                 } else {                                 // a (K-2)-mer: a (K-1)-mer below it whose four children are all zero
-                                    const uint32_t zz = ((g.x & 0xFFFFu) == 0u ? 1u : 0u) | ((g.x >> 16) == 0u ? 2u : 0u) |
-                                                        ((g.y & 0xFFFFu) == 0u ? 4u : 0u) | ((g.y >> 16) == 0u ? 8u : 0u);
+                                    uint32_t zz = ((g.x & 0xFFFFu) == 0u ? 1u : 0u) | ((g.x >> 16) == 0u ? 2u : 0u) |
+                                                  ((g.y & 0xFFFFu) == 0u ? 4u : 0u) | ((g.y >> 16) == 0u ? 8u : 0u);
+                                    // (SIDE: the (K-1)-mer x0..x5 x2 may occur through its period-4 child although its four counters are zero)
+                                    if (SIDE && ((q6 ^ (q6 >> 8)) & 0xFu) == 0u) zz &= ~(1u << ((q6 >> 6) & 3u));
                                     if (zz) slot = ((q6 << 2) | uint32_t(__ffs(int(zz)) - 1)) << 2;
                                 }
                             } else {
@@ -842,9 +897,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     // read here - thread t owns 128 (256) contiguous table bytes; which 5-mer comes first and which 16 bytes of it
                     // rotate with the lane, so that the eight lanes of a bank group never meet (a b128 read takes eight passes anyway)
                     uint32_t c5[4] = {0u, 0u, 0u, 0u}, j5[4] = {0u, 1u, 2u, 3u};
+                    uint32_t side_mine = 0;             // SIDE: the count of the period-4 max-mer (q4)(q4)
                     if constexpr (LV == 5) {
                         const uint2 ch = *reinterpret_cast<const uint2*>(small16 + ox[5] + 4 * q4);     // D_5 (fused) or C_5, four u16
                         if constexpr (FUSED) {
+                            // (SIDE: the period-4 max-mer (q4)(q4) sits below the thread's (K-3)-mer 4 q4 + x0)
+                            if constexpr (SIDE) { side_mine = side8[q4]; extra += uint64_t(side_mine) << (16u * (q4 >> 6)); }
                             const uint64_t d64 = ((uint64_t(ch.y) << 32) | ch.x) + extra;
                             const unsigned char* mine = t8b + q4 * (BITS == 8 ? 256u : 128u);
                             // (all of the thread's table bytes requested before the first is summed: one LDS round trip, not eight)
@@ -859,7 +917,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                                     x[m][h] = *reinterpret_cast<const uint4*>(mine + j * (BITS == 8 ? 64u : 32u) + hh * 16u);
                                 }
                             }
-                            uint32_t tot = 0;
+                            uint32_t tot = side_mine;
 #pragma unroll
                             for (int m = 0; m < 4; ++m) {
                                 const uint32_t j = (uint32_t(m) + uint32_t(tid)) & 3u;
@@ -951,7 +1009,10 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         }
                         if constexpr (FUSED) {          // (the four entries in the lane's rotated order)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) put_pre(4 * q4 + j5[m], A5[m], W5[m]);
+                            for (int m = 0; m < 4; ++m) put_pre(4 * q4 + j5[m], A5[m], W5[m], side_mine);
+                            // (a side count beyond the scoring loop's {1/c, c^2 r_K} table; the sample of the adaptive width counts these
+                            //  windows: they would have wrapped a 4-bit counter without the side table)
+                            if (SIDE && side_mine >= 16u) atomicOr(&misc[M8_PMASK], 0x80000000u);
                         } else {
                             auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
                             auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
@@ -989,7 +1050,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             __syncthreads();
             STAMP(5)
-            const uint32_t placed = PLACE ? uni(misc[M8_PMASK]) : 0u;               // entries of the orphan list that went into the table
+            const uint32_t pmask_raw = PLACE ? uni(misc[M8_PMASK]) : 0u;
+            const uint32_t placed = pmask_raw & 0x7FFFFFFFu;                        // entries of the orphan list that went into the table
             if constexpr (PLACE) {
                 if (pend0 != 0xFFFFFFFFu) orph[pend0 >> 16] = uint16_t(pend0);
                 if (pend1 != 0xFFFFFFFFu) orph[pend1 >> 16] = uint16_t(pend1);
@@ -1009,6 +1071,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     remove_fakes(); hand_over(); continue;
                 }
             }
+            // (the sample of the adaptive width: windows that reach the scoring loop, and those among them that a plain 4-bit table would
+            //  have handed on - a side count of 16+)
+            if (SIDE && (ROLE & 1) && tid == 0) { atomicAdd(P.out_count + 3, 1u); if (pmask_raw >> 31) atomicAdd(P.out_count + 2, 1u); }
             load_orphans(placed);
 
             if (DEBUG && P.dbg_counts) {
@@ -1058,11 +1123,25 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // One position, its counts known.  `sel`: the position's index into the {1/c, c^2 r_K} table - its top count, or 0
             // where it starts no max-mer: such a position scores the stand-in code (a real max-mer of this window: finite values)
             // with weight 0 and adds exactly +0.0 to every sum, so no term needs a mask.
-            auto score_one = [&](const Fetched& f, uint32_t c8, uint32_t c7, uint32_t c6, uint32_t sel, bool on)
+            // (`big_c`, SIDE: some side count of this window is beyond the {1/c, c^2 r_K} table - window-uniform, so the windows without
+            //  one - all of them on sequence without simple repeats - run copies of the loop without the test)
+            auto score_one = [&](const Fetched& f, uint32_t c8, uint32_t c7, uint32_t c6, uint32_t sel, bool on, auto big_c)
                                  __attribute__((always_inline)) {
                 double2 rs;                                                   // {1/c8 (1.0 for the 19 in 20 max-mers seen once), c8^2 r8}
-                if constexpr (BITS == 4) rs = rstab[sel & 15u];
-                else {
+                if constexpr (BITS == 4) {
+                    rs = rstab[sel & 15u];
+                    if constexpr (SIDE && decltype(big_c)::value) {               // a side count beyond the table: as the 8-bit form
+                        if (__builtin_expect(__any(c8 >= 16u), 0)) {
+                            if (on && c8 >= 16u) {
+                                const double dc = double(c8);
+                                double r = __builtin_amdgcn_rcp(dc);
+                                r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                                r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                                rs = make_double2(r, double(__umul24(c8, c8)) * r8);
+                            }
+                        }
+                    }
+                } else {
                     rs = make_double2(rctab[sel & 15u], double(__umul24(sel, sel)) * r8);     // (the same product, rounded alike)
                     if (__builtin_expect(__any(c8 >= 16u), 0)) {              // (wave-uniform, rare: low-complexity sequence)
                         if (on && c8 >= 16u) {                                // beyond the table: reciprocal + two Newton steps
@@ -1101,6 +1180,12 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             asm volatile("" : "+v"(ah), "+v"(al), "+v"(fm4));
             const uint64_t acode4 = (uint64_t(ah) << 32) | al;
             auto raw4_at = [&](int it) -> uint32_t { return uint32_t(acode4 >> (64 - 2 * K - 2 * it)) & (NK - 1u); };
+            // SIDE: the period test of all the lane's positions in one go - the low byte of the max-mer at position `it`, in
+            // acode4 ^ (acode4 >> 8), is its bases 4..7 xor its bases 0..3.  (A position that starts no max-mer scores a stand-in code
+            // with weight 0 and adds +0.0 to every sum whatever counts it reads - finite is all they need to be - so the scoring
+            // loop takes the position's own period byte there too: no select.)
+            const uint64_t aper = SIDE ? (acode4 ^ (acode4 >> 8)) : 0ull;
+            auto per4_at = [&](int it) -> uint32_t { return SIDE ? (uint32_t(aper >> (64 - 2 * K - 2 * it)) & 0xFFu) : 0xFFFFFFFFu; };
             // Shape of the scoring loop, measured per K (bench shard / C2 shape, M windows/s):
             //   K = 8 (LDS allows 3 / 2 workgroups per CU): unrolled, groups of 2: 44.8 / 36.2; rolled, groups of 1: 43.2 / 35.6
             //   K = 6, 7 (tables of 4 / 16 KiB: registers bound the occupancy): unrolled at 3 per CU spills (26 / 24); rolled,
@@ -1108,7 +1193,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #ifdef FRISK8_S4_GROUP
             constexpr int GR = FRISK8_S4_GROUP;
 #else
-            constexpr int GR = (K == 8 && BITS == 4) ? 2 : 1;       // (8-bit form at K = 8: groups of one are 2..3 % ahead)
+            constexpr int GR = (K == 8 && BITS == 4 && !SIDE) ? 2 : 1;       // (8-bit form at K = 8: groups of one are 2..3 % ahead; SIDE: registers)
 #endif
 #ifdef FRISK8_ROLLED
             constexpr bool ROLLED = FRISK8_ROLLED != 0;
@@ -1121,7 +1206,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             //  wave whose lanes all read the ring has nothing new to park, and its loop carries neither the select nor the store.
             //  Stores cost more than they look in this loop: loads and stores return in order on one counter, so every load behind a
             //  store waits for the store's acknowledgement - measured 1.1 ms per scan with every wave parking)
-            auto score_all = [&](auto allon_c, auto orph_c, auto park_c) __attribute__((always_inline)) {
+            auto score_all = [&](auto allon_c, auto orph_c, auto park_c, auto big_c) __attribute__((always_inline)) {
                 constexpr bool ALLON = decltype(allon_c)::value;
                 constexpr bool PARK = RING && decltype(park_c)::value;
                 constexpr int FMODE = PARK ? 2 : 1;
@@ -1140,7 +1225,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     uint32_t c8[GR], c7[GR], c6[GR];
 #pragma unroll
                     for (int k = 0; k < GR; ++k) {
-                        if (!CHECK || g + k < ITS) table_counts(f[k], code4_at(g + k), c8[k], c7[k], c6[k]);
+                        if (!CHECK || g + k < ITS) table_counts(f[k], code4_at(g + k), c8[k], c7[k], c6[k], per4_at(g + k));
                     }
 #pragma unroll
                     for (int k = 0; k < GR; ++k) {
@@ -1168,7 +1253,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                                 if constexpr (PARK_LATE) parked[g + k] = v;      // (unrolled form: stored behind the loop)
                                 else *reinterpret_cast<double*>(ring + f[k].roff) = v;
                             }
-                            score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
+                            score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k), big_c);
                         }
                     }
                 };
@@ -1176,7 +1261,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 // The rolled form: two groups per trip, ping-pong buffers (ITS is a multiple of 2 GR for GR = 1, 2); it needs
                 // 86..129 registers and no scratch, but measured 4..6 % slower at K = 8 and three workgroups per CU; thread counts
                 // of 320 / 384 / 512 per workgroup 18..60 % slower.
-                if constexpr (ROLLED && ITS % (2 * GR) == 0) {
+                // (SIDE, windows with a side count beyond the table: the unrolled form with the test for it in every position spills into
+                //  scratch - and a scratch store in this loop holds every later load back like a parking store - so these take the rolled form)
+                if constexpr ((ROLLED || (SIDE && decltype(big_c)::value)) && ITS % (2 * GR) == 0) {
                     Fetched bufA[GR], bufB[GR];
 #pragma unroll
                     for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(k), k, FMODE);
@@ -1218,18 +1305,21 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const bool wave_parks = RING && __any(lane_new);                // (wave-uniform)
             using yes = std::true_type;
             using no = std::false_type;
+            // (SIDE: a window with a side count of 16+ - bit 31 of the mask word, set in stage 3 - takes the copies with the test for it)
+            const bool side_big = SIDE && (pmask_raw >> 31);
             if constexpr (PLACE) {
-                if (n_list == 0) {              // (every orphan found room in the table: nearly every window)
-                    if (__all(fm4 == ALL_MINE)) { if (wave_parks) score_all(yes{}, orphX{}, yes{}); else score_all(yes{}, orphX{}, no{}); }
-                    else { if (wave_parks) score_all(no{}, orphX{}, yes{}); else score_all(no{}, orphX{}, no{}); }
-                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{});
-                else score_all(no{}, orphN{}, yes{});
+                if (n_list == 0 && !side_big) {              // (every orphan found room in the table: nearly every window)
+                    if (__all(fm4 == ALL_MINE)) { if (wave_parks) score_all(yes{}, orphX{}, yes{}, no{}); else score_all(yes{}, orphX{}, no{}, no{}); }
+                    else { if (wave_parks) score_all(no{}, orphX{}, yes{}, no{}); else score_all(no{}, orphX{}, no{}, no{}); }
+                } else if (n_list == 0) { if (wave_parks) score_all(no{}, orphX{}, yes{}, yes{}); else score_all(no{}, orphX{}, no{}, yes{}); }
+                else if (n_list <= 4) score_all(no{}, orph4{}, yes{}, yes{});
+                else score_all(no{}, orphN{}, yes{}, yes{});
             } else {
                 if (n_list <= 2 && n7 <= 1) {       // (every window without invalid bases)
-                    if (__all(fm4 == ALL_MINE)) score_all(yes{}, orph2{}, yes{});
-                    else score_all(no{}, orph2{}, yes{});
-                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{});
-                else score_all(no{}, orphN{}, yes{});
+                    if (__all(fm4 == ALL_MINE)) score_all(yes{}, orph2{}, yes{}, yes{});
+                    else score_all(no{}, orph2{}, yes{}, yes{});
+                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{}, yes{});
+                else score_all(no{}, orphN{}, yes{}, yes{});
             }
 
             // workgroup totals in a fixed order: DPP butterfly per wave, then the NW partials in wave order

@@ -284,13 +284,13 @@ class Engine:
         self._check(self._lib.frisk_scan_plan(self._ctx, int(w), int(inc), flags, C.byref(n)))
         return int(n.value)
 
-    def scan(self, w, inc, rip=False, scaffolds_all=False, c0=0, c1=-1, debug=False, pinned=False, chunks=False, bits4=False):
+    def scan(self, w, inc, rip=False, scaffolds_all=False, c0=0, c1=-1, debug=False, pinned=False, chunks=False, bits4=False, side4=False):
         """Score candidates [c0, c1).  chunks=True: the schedule of a long scan (chunks of 8 windows, tables sliding inside a
-        chunk) whatever the size; bits4=True: K = 8 starts with 4-bit counters whatever the size - same rows either way.  With pinned=True the result arrays are views of page-locked buffers owned
+        chunk) whatever the size; bits4=True: K = 8 starts with 4-bit counters whatever the size, side4=True: ... with the side table for max-mers of period <= 4 - same rows either way.  With pinned=True the result arrays are views of page-locked buffers owned
         by the engine: D2H at PCIe rate and no per-call allocation, but the views are only valid until the next
         scan() on this engine.  pinned=False (default) returns ordinary numpy arrays."""
         flags = (_ffi.SCAN_RIP if rip else 0) | (_ffi.SCAN_SCAFFOLDS_ALL if scaffolds_all else 0) | (_ffi.SCAN_CHUNKS if chunks else 0) | \
-                (_ffi.SCAN_BITS4 if bits4 else 0)
+                (_ffi.SCAN_BITS4 if bits4 else 0) | (_ffi.SCAN_SIDE4 if side4 else 0)
         total = self.scan_plan(w, inc, scaffolds_all)
         if c1 < 0:
             c1 = total
@@ -333,6 +333,10 @@ class Engine:
     def scan_stat(self):
         """(counter width of the bulk launch, windows handed 4->8 bit, windows handed on to 16 bit, row segments) of the last scan."""
         return tuple(int(self._lib.frisk_last_scan_stat(self._ctx, i)) for i in range(4))
+
+    def scan_side(self):
+        """True when the last scan's 4-bit bulk launch counted the max-mers of period <= 4 in its side table."""
+        return int(self._lib.frisk_last_scan_stat(self._ctx, 4)) == 1
 
     def kernel_ms(self, which=0):
         return float(self._lib.frisk_last_kernel_ms(self._ctx, which))

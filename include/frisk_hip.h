@@ -48,6 +48,9 @@ enum {
 #define FRISK_SCAN_BITS4        512u /* K = 8: the bulk launch with 4-bit counters whatever the scan's size, overflowing windows handed on
                                         to the 8- and 16-bit forms (a short scan otherwise starts at 8 bits; a long one samples first).
                                         Results are the same bits. */
+#define FRISK_SCAN_SIDE4       1024u /* K = 8: as FRISK_SCAN_BITS4, with the side table for the max-mers of period <= 4 (poly-A, (CA)n, (AAAT)n
+                                        ...) beside the 4-bit counters where the windows slide - the form a long scan of repeat-rich
+                                        sequence picks by itself.  Results are the same bits. */
 
 /* per-row status bits written to `status` by frisk_scan */
 #define FRISK_ROW_KEPT        1u      /* window passed the < 30 % non-ACGT filter (L237-241)          */
@@ -198,7 +201,8 @@ int frisk_scan_ivom(frisk_ctx* ctx, int32_t w, int32_t inc, uint32_t flags, int6
  * 4- or 8-bit counters and hands a window with a more frequent max-mer (low-complexity sequence) to the next wider form:
  * which = 0: counter width of the bulk launch (4 or 8; 16 = the narrow kernel was not used),
  *         1: windows handed from 4-bit to 8-bit counters,   2: windows handed on to 16-bit counters,
- *         3: row segments (2: the last sixteenth of a long scan ran on a second stream while the rows of the rest went to the host). */
+ *         3: row segments (2: the last sixteenth of a long scan ran on a second stream while the rows of the rest went to the host),
+ *         4: 1 = the 4-bit bulk launch counted the max-mers of period <= 4 in its side table (FRISK_SCAN_SIDE4 / picked by the sample). */
 int64_t frisk_last_scan_stat(const frisk_ctx* ctx, int which);
 
 /* The rows of the score table as text, exactly as the reference's scan loop writes them (L1487-1494): tab-separated

@@ -425,8 +425,8 @@ def test_full_size_rows_against_c_oracle(shape):
             assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
             checked += len(k)
         assert checked > (5000 if shape != "C1" else 40)
-        if shape == "C5/8 unmasked repeats":        # the path real assemblies take: 8-bit counters for the bulk of the scan
-            assert e.scan_stat()[0] == 8
+        if shape == "C5/8 unmasked repeats":        # the path real assemblies take: 4-bit counters + the side table for period-4 max-mers
+            assert e.scan_stat()[0] == 4 and e.scan_side()
 
 
 @pytest.mark.parametrize("want_rip", [False, True])
@@ -508,37 +508,41 @@ def test_windows_beyond_lds_counters_against_c_oracle(kmin, kmax, w, inc, scaffo
     assert np.array_equal(res.kld, res2.kld, equal_nan=True) and np.array_equal(res.status, res2.status)
 
 
-def _genome_with_repeats(n, every):
+def _genome_with_repeats(n, every, units=(b"A", b"T", b"CA", b"TG", b"AAT", b"GATA", b"TTAGGG"), lens=(24, 40, 60, 90, 300, 700)):
     """One synthetic scaffold with microsatellites and poly-A runs sprinkled in, one about every `every` bases - a few of
     them longer than 8-bit counters hold."""
     from frisk_amd import synth
     s = np.frombuffer(synth.scaffold(n, 77, 0, island_frac=0.05, n_frac=0.01, lower_frac=0.01), dtype=np.uint8).copy()
     rng = np.random.default_rng(every)
-    units = [b"A", b"T", b"CA", b"TG", b"AAT", b"GATA", b"TTAGGG"]
     for a in range(5000, n - 3000, every):
         a += int(rng.integers(0, every // 3))
         u = units[int(rng.integers(0, len(units)))]
-        ln = int(rng.choice([24, 40, 60, 90, 300, 700]))                       # 300+: wraps 8-bit counters as well
+        ln = int(rng.choice(lens))                                             # 300+: wraps 8-bit counters as well
         rep = (u * (ln // len(u) + 1))[:ln]
         s[a:a + ln] = np.frombuffer(rep, dtype=np.uint8)
     return [s.tobytes()]
 
 
-@pytest.mark.parametrize("every,expect_bulk", [(60000, 4), (9000, 8)])
-def test_adaptive_counter_width_and_handover(every, expect_bulk):
+@pytest.mark.parametrize("every,units,expect_bulk,expect_side", [
+    (60000, None, 4, False), (9000, None, 8, False), (9000, (b"A", b"T", b"CA", b"TG", b"GATA", b"AAAT"), 4, True)])
+def test_adaptive_counter_width_and_handover(every, units, expect_bulk, expect_side):
     """The default K = 8 kernel counts max-mers in 4- or 8-bit counters (scan8_kernel.h) and hands windows with a more
     frequent max-mer to the next wider form: 4-bit -> 8-bit -> 16-bit.  A 12 Mb genome with microsatellites and poly-A
     runs (a few of them longer than 8-bit counters hold) sprinkled in: every row must still equal the compiled oracle's,
-    the hand-over lists must have been used, and the sample must have picked the expected width for the bulk."""
+    the hand-over lists must have been used, and the sample must have picked the expected form for the bulk: plain 4-bit
+    counters where repeats are sparse, 8-bit counters where they are dense and many of them of periods 3 or 6 or longer than
+    255 copies, 4-bit counters with the side table for max-mers of period <= 4 where dense repeats are mostly of that kind."""
     from oracle import frisk_oracle_c as OC
     from frisk_amd import _ffi
-    seqs = _genome_with_repeats(12_000_000, every)
+    # (the side-table form exists for launches whose windows slide: scans of 12 288+ windows on this GPU)
+    seqs = _genome_with_repeats(12_000_000, every) if units is None else _genome_with_repeats(14_000_000, every, units, (24, 40, 60, 90, 150, 700))
     with make_engine(1, 8) as e:
         e.load(seqs)
         e.profile_reset(); e.profile_add(); e.profile_finalize()
         sym, tl, ex, nn = e.profile_get()
         res = e.scan(5000, 1000, rip=True)
         stat = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
+        sided = e.scan_side()
         sub = e.scan(5000, 1000, rip=True, c0=1234, c1=4321)                   # another range: another sample, other widths
         few = e.scan(5000, 1000, rip=True, c0=700, c1=1000)                     # same batch and geometry: the first sample's choice holds
         stat_few = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
@@ -546,7 +550,7 @@ def test_adaptive_counter_width_and_handover(every, expect_bulk):
         e.profile_reset(); e.profile_add(); e.profile_finalize()
         other = e.scan(5000, 1000, rip=True, c0=2000, c1=2900)                  # ... and 900 windows are too few to sample: 8-bit bulk
         stat_other = [int(_ffi.lib().frisk_last_scan_stat(e._ctx, i)) for i in range(3)]
-    assert stat[0] == expect_bulk, stat
+    assert stat[0] == expect_bulk and sided == expect_side, (stat, sided)
     assert stat[1] > 50 and stat[2] > 5, stat                                  # both hand-over lists were used
     assert stat_few[0] == expect_bulk, stat_few
     for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):        # same bits whichever form scored the window

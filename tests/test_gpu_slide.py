@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 COLS = ("seq_index", "start", "stop", "status", "kld", "gc")
 HANDED = []
+SIDED = []
 
 
 def _same_bits(a, b, rip, tag):
@@ -96,7 +97,14 @@ def test_sliding_tables_equal_fresh_counts_and_the_oracle(block):
             if c["kmax"] == 8:      # 4-bit counters first (what a long scan of sequence without long repeats does): hand-overs
                 narrow = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"], chunks=True, bits4=True)
                 _same_bits(fresh, narrow, c["rip"], tag + " (4-bit bulk)")
-                handed += e.scan_stat()[1]
+                handed_plain = e.scan_stat()[1]
+                handed += handed_plain
+                # ... and with the side table for the max-mers of period <= 4 beside them (what a long scan of repeat-rich sequence does)
+                sided = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"], chunks=True, side4=True)
+                _same_bits(fresh, sided, c["rip"], tag + " (4-bit bulk + side table)")
+                if n > 0 and 2 * c["inc"] <= c["w"] - 7:
+                    assert e.scan_side() and e.scan_stat()[0] == 4, tag
+                    SIDED.append((e.scan_stat()[1], handed_plain))
             if n > 12:       # another range: the chunks start elsewhere, other windows are slid into
                 c0 = int(rng.integers(1, 8))
                 part = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"], c0=c0, c1=n - 1, chunks=True)
@@ -119,3 +127,7 @@ def test_some_windows_overflowed_four_bits():
     """(runs after the blocks above) the poly-X / microsatellite inserts did wrap 4-bit counters somewhere: the hand-over chain
     4-bit -> 8-bit -> 16-bit was part of what was compared."""
     assert not HANDED or sum(HANDED) > 0
+    # ... and the side table kept most of them on the 4-bit form (poly-X and microsatellites of period <= 4 are what the cases insert)
+    if SIDED:
+        with_side, plain = sum(a for a, _ in SIDED), sum(b for _, b in SIDED)
+        assert with_side < plain, (with_side, plain)
