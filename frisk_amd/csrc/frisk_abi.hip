@@ -30,7 +30,7 @@
 #define FRISK_K7_WPS 4              // waves per SIMD (= 256-thread workgroups per CU) of the K = 6, 7 narrow-counter kernels
 #endif
 #ifndef FRISK_SIDE_SHARE
-#define FRISK_SIDE_SHARE 0.08       // 4-bit bulk takes the side-table form when the plain form would hand on more than this share of the sample
+#define FRISK_SIDE_SHARE 0.06       // 4-bit bulk takes the side-table form when the plain form would hand on more than this share of the sample
 #endif
 #ifndef FRISK_K8_WIDTH
 #define FRISK_K8_WIDTH 0            // order-8 counters of the default K = 8 path (scan8_kernel.h): 0 = adaptive 4/8 bits, 4, 8, 16 = off
@@ -1383,8 +1383,8 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             // 9.98 ms, 8-bit bulk 8.51 / 8.57 / 8.71 / 8.78 ms - tools/exp/width_sweep.sh)
             bulk = (double(handed) <= 0.3 * double(nsample * chunk8)) ? 4 : 8;
             // ... and the side table pays when the plain form would hand on more than FRISK_SIDE_SHARE of the windows that are scored
-            // (measured on the bench shard: it costs a scored window 1.6 ns - ten instructions per position -, a window handed on
-            // 18 ns - a skeleton and a second scoring without sliding: tools/exp/side_rate.py)
+            // (measured on the bench shard: it costs a scored window 1.0 ns - ten instructions per position: 6.97 against 6.59 ms per
+            // scan -, a window handed on 18 ns - a skeleton and a second scoring without sliding: tools/exp/side_rate.py)
             side = bulk == 4 && side_ok && double(handed + sampled[2]) > FRISK_SIDE_SHARE * double(handed + sampled[3]);
             if (const char* ev = tune_env("FRISK_SIDE")) side = side_ok && bulk == 4 && std::atoi(ev) != 0;
             sel_mode = 2;

@@ -81,13 +81,14 @@ struct Lds8 {
     static constexpr uint32_t orphans = small + small_bytes;                       // u16[FRISK8_ORPH_CAP]
     static constexpr uint32_t NL = 1u << (2 * (KMAX - 3));                         // entries of the shared prefix tables (level KMAX-3)
     static constexpr uint32_t pre = (orphans + FRISK8_ORPH_CAP * 2 + 15) / 16 * 16;     // Pre8[NL]: the shared prefix sums, 12 bytes each
-    // SIDE (below): the weights of the prefix sums are 8-byte entries {W, the side count of the (K-3)-mer's 4-mer}, and the side table follows
-    // (8-bit side counters: LDS is handed out in pieces of 1280 bytes on gfx950, three workgroups per CU get 42 of them each = 53 760)
-    static constexpr uint32_t side = pre + NL * (SIDE ? 16 : 12);                  // u8[256]: counts of the period-4 max-mers (SIDE)
+    // SIDE (below): the side table follows the prefix sums (whose weights carry the side count of the (K-3)-mer's 4-mer in their top bits)
+    // (LDS is handed out in pieces of 1280 bytes on gfx950: three workgroups per CU get 42 of them each = 53 760 bytes)
+    static constexpr uint32_t side = pre + NL * 12;                                // u8[256]: counts of the period-4 max-mers (SIDE)
     static constexpr uint32_t logtab = side + (SIDE ? 256 : 0);                    // {1/c_i, -ln(1/c_i)} x LOGN
     // {1/c, c^2 r_K} for c < 16 (second half per window); the 8-bit form has 128 bytes to spare, not 256: 1/c only, the other computed
     static constexpr uint32_t rctab = logtab + uint32_t(LOGN) * 16;
-    static constexpr uint32_t misc = rctab + 16 * (BITS == 4 ? 16 : 8);            // counters x2, then one {Sw, Sg, T} per wave
+    // (SIDE: {1/c, c^2 r_K} for c < 256 - a side count goes up to 255)
+    static constexpr uint32_t misc = rctab + (SIDE ? 256 * 16 : 16 * (BITS == 4 ? 16 : 8));     // counters x2, then one {Sw, Sg, T} per wave
     static constexpr uint32_t t8 = (misc + 2 * FRISK8_SLOTS * 4 + uint32_t(NT / 64) * 3 * 8 + 15) / 16 * 16;
     static constexpr uint32_t t8_bytes = (1u << (2 * KMAX)) * BITS / 8;
     static constexpr uint32_t total = t8 + t8_bytes;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     constexpr int NW = NT / 64;
     constexpr int SHW = BITS == 8 ? 2 : 3;               // code >> SHW = dword of the table
     constexpr uint32_t PERM = (32 / BITS) - 1;           // code & PERM = field inside the dword
-    static_assert(!SIDE || (KMAX == 8 && BITS == 4 && !DEBUG && NT == 256), "the side table exists for the 4-bit form at K = 8");
+    static_assert(!SIDE || (KMAX == 8 && BITS == 4 && !DEBUG && NT == 256 && FRISK8_PRE_SPLIT), "the side table exists for the 4-bit form at K = 8");
     using L = Lds8<KMAX, BITS, LOGN, NT, SIDE>;
     // the order-K table is cleared whole when that takes no more stores per thread than a lane has positions (measured: 64 KiB
     // for windows of 2000 bases is the one case where every position clearing its own dword is cheaper)
@@ -189,18 +190,19 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     //   * stage 1 sends a position with such a max-mer to side[y] instead of the table (same for the sliding updates);
     //   * stage 3: thread t holds the 4-mer t, so side[t] is ITS count - one of the 64 max-mers below its (K-3)-mer 4 t + x0: it
     //     adds side[t] there (and to the table's grand total), which makes every order <= K-3 right, and stores side[t]
-    //     beside the weight of each of its four (K-3)-mers' prefix sums: the scoring loop's read of W brings it along;
+    //     in the top bits of the weight of each of its four (K-3)-mers' prefix sums: the scoring loop's read of W brings it along;
     //   * stage 4: the only period-4 max-mer below the (K-2)-mer x0..x5 of a position is (x0 x1 x2 x3)^2 - if x4 x5 = x0 x1 -, and
     //     likewise for its (K-1)-mer (x4 x5 x6 = x0 x1 x2) and the max-mer itself: with t = (code ^ code >> 8) & 0xFF the side
     //     count joins c_{K-2} if t < 16, c_{K-1} if t < 4, c_K if t = 0 - as the start values of the sums that are there anyway;
-    //   * a count beyond 15 takes the reciprocal and the top order's term the way the 8-bit form computes them (same bits).
+    //   * {1 / c_K, c_K^2 r_K} come from a table of 256 entries instead of 16 - the reciprocals made once per workgroup with the
+    //     8-bit form's instruction sequence for counts beyond 15, the products per window as before: the same bits.
     // Max-mers that are NOT of period <= 4 and occur 16+ times still wrap their counter: grand-total test, hand-over, as before -
     // and so does a side counter at 256 (the side counts are part of the grand total): a window with a max-mer that occurs 256+ times
     // is the 16-bit form's whichever form the bulk runs in - a property of the window, so rows do not depend on the launch's shape.
     uint32_t* side32 = reinterpret_cast<uint32_t*>(lds + L::side);
     const unsigned char* side8 = lds + L::side;
     auto put_pre = [&](uint32_t idx, double A, uint32_t W, uint32_t sd = 0u) __attribute__((always_inline)) {
-        if constexpr (SIDE) { preA[idx] = A; reinterpret_cast<uint2*>(preW)[idx] = make_uint2(W, sd); }
+        if constexpr (SIDE) { preA[idx] = A; preW[idx] = W | (sd << 23); }     // (W < 5120 (4 + 16 + ... + 4^5) < 2^23; the side count < 2^8)
         else if (FRISK8_PRE_SPLIT) { preA[idx] = A; preW[idx] = W; } else { pre[idx].A = A; pre[idx].W = W; }
     };
     // (stage 1) one max-mer position more (SIGN = +1) or less (-1): the table's field, or the side counter of a period-4 max-mer
@@ -237,7 +239,19 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     {
         double2* lt = reinterpret_cast<double2*>(lds + L::logtab);
         for (int i = tid0; i < LOGN; i += NT) lt[i] = reinterpret_cast<const double2*>(LOGN == 128 ? P.log_tab : (LOGN == 64 ? P.log_tab64 : P.log_tab32))[i];
-        if (tid0 < 16) {
+        if constexpr (SIDE) {
+            static_assert(!SIDE || NT >= 256, "one thread per entry of the reciprocal table");
+            if (tid0 < 256) {
+                double r = P.rc_tab[tid0 & 15];
+                if (tid0 >= 16) {                       // reciprocal + two Newton steps: the 8-bit form's sequence for a count beyond its table
+                    const double dc = double(tid0);
+                    r = __builtin_amdgcn_rcp(dc);
+                    r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                    r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
+                }
+                rstab[tid0] = make_double2(r, 0.0);
+            }
+        } else if (tid0 < 16) {
             if (BITS == 4) rstab[tid0] = make_double2(P.rc_tab[tid0], 0.0); else rctab[tid0] = P.rc_tab[tid0];
         }
     }
@@ -719,7 +733,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             };
             // what a max-mer position reads, all of it addressed by the code alone (so it can be fetched ahead of use):
             // genome-side value, the order-8 counters of its 6-mer / 7-mer / itself, the shared-prefix sums
-            struct Fetched { double Ig, A5; uint32_t W5, c8, w7, roff, sd; uint4 w6; };       // (sd: SIDE - the side count of the code's 4-mer)
+            struct Fetched { double Ig, A5; uint32_t W5, c8, w7, roff; uint4 w6; };       // (SIDE: W5 carries the side count of the code's 4-mer in its top bits)
             // (`it`: the lane's position the code belongs to, whose genome-side value waits in the ring - a 1.0 where the position
             //  starts no max-mer: the stand-in it scores has weight 0, any finite number will do;
             //  mode: 0 counts only; 1 the scoring loop of a wave whose lanes all read the ring; 2 ... of a wave with lanes that gather)
@@ -749,12 +763,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     const uint2 x = *reinterpret_cast<const uint2*>(t8b + ((c16 >> 4) << 3));
                     f.w6 = make_uint4(x.x, x.y, 0u, 0u);
                 }
-                f.sd = 0;
-                if constexpr (SIDE) {
-                    const uint2 ws = *reinterpret_cast<const uint2*>(lds + L::pre + NL * 8 + ((c16 >> 6) << 3));
-                    f.W5 = ws.x; f.sd = ws.y;
-                    f.A5 = *reinterpret_cast<const double*>(lds + L::pre + ((c16 >> 6) << 3));
-                } else if (FRISK8_PRE_SPLIT) {
+                if (FRISK8_PRE_SPLIT) {
                     f.W5 = *reinterpret_cast<const uint32_t*>(lds + L::pre + NL * 8 + ((c16 >> 6) << 2));
                     f.A5 = *reinterpret_cast<const double*>(lds + L::pre + ((c16 >> 6) << 3));
                 } else {
@@ -783,7 +792,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     uint32_t s6 = 0u, s7 = 0u, s8 = 0u;
                     if constexpr (SIDE) {
                         const uint32_t t = tper != 0xFFFFFFFFu ? tper : ((c16 ^ (c16 >> 8)) & 0xFFu);
-                        s6 = t < 16u ? f.sd : 0u; s7 = t < 4u ? f.sd : 0u; s8 = t == 0u ? f.sd : 0u;
+                        const uint32_t sd = f.W5 >> 23;
+                        s6 = t < 16u ? sd : 0u; s7 = t < 4u ? sd : 0u; s8 = t == 0u ? sd : 0u;
                     }
                     c8 = __builtin_amdgcn_ubfe(w7, (c16 & 3u) * 4u, 4u) + s8;
                     c7 = __builtin_amdgcn_udot8(w7, 0x1111u, s7, false);
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                                         __builtin_amdgcn_readlane(__double2loint(r_lane), x));
             };
             // the top order's terms by count: {1 / c, c^2 r_K} for c < 16 (c = 0: a position that starts no max-mer, weight 0)
-            if (BITS == 4 && tid < 16) rstab[tid].y = double(uint32_t(tid * tid)) * r_of(K);
+            if (BITS == 4 && (SIDE || tid < 16)) rstab[tid & 255].y = double(uint32_t((tid & 255) * (tid & 255))) * r_of(K);     // (SIDE: 256 entries)
             {
                 constexpr int LV = LVL;
                 double rx[LV + 1];
@@ -1010,9 +1020,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         if constexpr (FUSED) {          // (the four entries in the lane's rotated order)
 #pragma unroll
                             for (int m = 0; m < 4; ++m) put_pre(4 * q4 + j5[m], A5[m], W5[m], side_mine);
-                            // (a side count beyond the scoring loop's {1/c, c^2 r_K} table; the sample of the adaptive width counts these
-                            //  windows: they would have wrapped a 4-bit counter without the side table)
-                            if (SIDE && side_mine >= 16u) atomicOr(&misc[M8_PMASK], 0x80000000u);
+                            // (the sample of the adaptive width counts the windows that would have wrapped a 4-bit counter without the side table)
+                            if (SIDE && (ROLE & 1) && side_mine >= 16u) atomicOr(&misc[M8_PMASK], 0x80000000u);
                         } else {
                             auto lo = [](double x) -> uint32_t { return uint32_t(__double2loint(x)); };
                             auto hi = [](double x) -> uint32_t { return uint32_t(__double2hiint(x)); };
@@ -1123,25 +1132,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // One position, its counts known.  `sel`: the position's index into the {1/c, c^2 r_K} table - its top count, or 0
             // where it starts no max-mer: such a position scores the stand-in code (a real max-mer of this window: finite values)
             // with weight 0 and adds exactly +0.0 to every sum, so no term needs a mask.
-            // (`big_c`, SIDE: some side count of this window is beyond the {1/c, c^2 r_K} table - window-uniform, so the windows without
-            //  one - all of them on sequence without simple repeats - run copies of the loop without the test)
-            auto score_one = [&](const Fetched& f, uint32_t c8, uint32_t c7, uint32_t c6, uint32_t sel, bool on, auto big_c)
+            auto score_one = [&](const Fetched& f, uint32_t c8, uint32_t c7, uint32_t c6, uint32_t sel, bool on)
                                  __attribute__((always_inline)) {
                 double2 rs;                                                   // {1/c8 (1.0 for the 19 in 20 max-mers seen once), c8^2 r8}
-                if constexpr (BITS == 4) {
-                    rs = rstab[sel & 15u];
-                    if constexpr (SIDE && decltype(big_c)::value) {               // a side count beyond the table: as the 8-bit form
-                        if (__builtin_expect(__any(c8 >= 16u), 0)) {
-                            if (on && c8 >= 16u) {
-                                const double dc = double(c8);
-                                double r = __builtin_amdgcn_rcp(dc);
-                                r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
-                                r = __builtin_fma(r, __builtin_fma(-dc, r, 1.0), r);
-                                rs = make_double2(r, double(__umul24(c8, c8)) * r8);
-                            }
-                        }
-                    }
-                } else {
+                if constexpr (BITS == 4) rs = rstab[sel & (SIDE ? 255u : 15u)];            // (SIDE, beyond 15: the 8-bit form's values)
+                else {
                     rs = make_double2(rctab[sel & 15u], double(__umul24(sel, sel)) * r8);     // (the same product, rounded alike)
                     if (__builtin_expect(__any(c8 >= 16u), 0)) {              // (wave-uniform, rare: low-complexity sequence)
                         if (on && c8 >= 16u) {                                // beyond the table: reciprocal + two Newton steps
@@ -1155,7 +1150,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 }
                 const uint32_t W = shl_add(c8, std::integral_constant<int, 2 * K>{},
                                            shl_add(c7, std::integral_constant<int, 2 * K - 2>{},
-                                                   shl_add(c6, std::integral_constant<int, 2 * K - 4>{}, f.W5)));
+                                                   shl_add(c6, std::integral_constant<int, 2 * K - 4>{}, SIDE ? (f.W5 & 0x7FFFFFu) : f.W5)));
                 // c^2 exactly, as integers (< 2^32), then 4^x / D_x times it; the top order's term comes rounded from the table
                 double A = __builtin_fma(double(__umul24(c6, c6)), r6, f.A5);
                 A = __builtin_fma(double(__umul24(c7, c7)), r7, A);
@@ -1206,7 +1201,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             //  wave whose lanes all read the ring has nothing new to park, and its loop carries neither the select nor the store.
             //  Stores cost more than they look in this loop: loads and stores return in order on one counter, so every load behind a
             //  store waits for the store's acknowledgement - measured 1.1 ms per scan with every wave parking)
-            auto score_all = [&](auto allon_c, auto orph_c, auto park_c, auto big_c) __attribute__((always_inline)) {
+            auto score_all = [&](auto allon_c, auto orph_c, auto park_c) __attribute__((always_inline)) {
                 constexpr bool ALLON = decltype(allon_c)::value;
                 constexpr bool PARK = RING && decltype(park_c)::value;
                 constexpr int FMODE = PARK ? 2 : 1;
@@ -1253,7 +1248,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                                 if constexpr (PARK_LATE) parked[g + k] = v;      // (unrolled form: stored behind the loop)
                                 else *reinterpret_cast<double*>(ring + f[k].roff) = v;
                             }
-                            score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k), big_c);
+                            score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
                         }
                     }
                 };
@@ -1261,9 +1256,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 // The rolled form: two groups per trip, ping-pong buffers (ITS is a multiple of 2 GR for GR = 1, 2); it needs
                 // 86..129 registers and no scratch, but measured 4..6 % slower at K = 8 and three workgroups per CU; thread counts
                 // of 320 / 384 / 512 per workgroup 18..60 % slower.
-                // (SIDE, windows with a side count beyond the table: the unrolled form with the test for it in every position spills into
-                //  scratch - and a scratch store in this loop holds every later load back like a parking store - so these take the rolled form)
-                if constexpr ((ROLLED || (SIDE && decltype(big_c)::value)) && ITS % (2 * GR) == 0) {
+                if constexpr (ROLLED && ITS % (2 * GR) == 0) {
                     Fetched bufA[GR], bufB[GR];
 #pragma unroll
                     for (int k = 0; k < GR; ++k) bufA[k] = fetch(code4_at(k), k, FMODE);
@@ -1305,21 +1298,18 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             const bool wave_parks = RING && __any(lane_new);                // (wave-uniform)
             using yes = std::true_type;
             using no = std::false_type;
-            // (SIDE: a window with a side count of 16+ - bit 31 of the mask word, set in stage 3 - takes the copies with the test for it)
-            const bool side_big = SIDE && (pmask_raw >> 31);
             if constexpr (PLACE) {
-                if (n_list == 0 && !side_big) {              // (every orphan found room in the table: nearly every window)
-                    if (__all(fm4 == ALL_MINE)) { if (wave_parks) score_all(yes{}, orphX{}, yes{}, no{}); else score_all(yes{}, orphX{}, no{}, no{}); }
-                    else { if (wave_parks) score_all(no{}, orphX{}, yes{}, no{}); else score_all(no{}, orphX{}, no{}, no{}); }
-                } else if (n_list == 0) { if (wave_parks) score_all(no{}, orphX{}, yes{}, yes{}); else score_all(no{}, orphX{}, no{}, yes{}); }
-                else if (n_list <= 4) score_all(no{}, orph4{}, yes{}, yes{});
-                else score_all(no{}, orphN{}, yes{}, yes{});
+                if (n_list == 0) {              // (every orphan found room in the table: nearly every window)
+                    if (__all(fm4 == ALL_MINE)) { if (wave_parks) score_all(yes{}, orphX{}, yes{}); else score_all(yes{}, orphX{}, no{}); }
+                    else { if (wave_parks) score_all(no{}, orphX{}, yes{}); else score_all(no{}, orphX{}, no{}); }
+                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{});
+                else score_all(no{}, orphN{}, yes{});
             } else {
                 if (n_list <= 2 && n7 <= 1) {       // (every window without invalid bases)
-                    if (__all(fm4 == ALL_MINE)) score_all(yes{}, orph2{}, yes{}, yes{});
-                    else score_all(no{}, orph2{}, yes{}, yes{});
-                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{}, yes{});
-                else score_all(no{}, orphN{}, yes{}, yes{});
+                    if (__all(fm4 == ALL_MINE)) score_all(yes{}, orph2{}, yes{});
+                    else score_all(no{}, orph2{}, yes{});
+                } else if (n_list <= 4) score_all(no{}, orph4{}, yes{});
+                else score_all(no{}, orphN{}, yes{});
             }
 
             // workgroup totals in a fixed order: DPP butterfly per wave, then the NW partials in wave order
