@@ -1456,8 +1456,18 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         const int64_t unit = chunk8 * P.sel_mod;
         int64_t cut = n;
         // (worth a second launch only when the rows' way to the host is long against a launch: 40 B x 128 K rows ~ 0.1 ms)
-        if (!debug && !c->want_ivom && n >= (int64_t(1) << 17) && n >= 64 * unit && !tune_env("FRISK_ONE_SEGMENT"))
+        if (!debug && !c->want_ivom && n >= (int64_t(1) << 17) && n >= 64 * unit && !tune_env("FRISK_ONE_SEGMENT")) {
             cut = (n / unit - std::max<int64_t>(1, n / unit / 16)) * unit;
+            // ... and the tail is a launch of its own: about a sixteenth of the windows is two chunks per workgroup - 1 616 chunks on 768
+            // workgroups left a tenth of them a third chunk and the others idle (0.78 ms under the profiler for 0.40 ms of work).  So
+            // the tail takes whole rounds: the largest number of chunks <= rounds x workgroups that the cut's alignment allows.
+            const int64_t wgs = int64_t(c->num_cu) * (bulk == 4 ? 3 : 2);
+            const int64_t tail_chunks = (n - cut + chunk8 - 1) / chunk8;
+            if (tail_chunks >= wgs && !tune_env("FRISK_TAIL_ANY")) {
+                const int64_t rounds = (tail_chunks + wgs / 2) / wgs;
+                cut = std::min(n - unit, (n - rounds * wgs * chunk8 + unit - 1) / unit * unit);
+            }
+        }
         rc = run_rows(0, 0, cut, c->stream, cut < n);
         if (rc) return rc;
         if (cut < n) {
