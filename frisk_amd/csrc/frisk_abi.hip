@@ -318,20 +318,22 @@ hipError_t launch_scan8(const ScanParams& P, int num_cu, int64_t work_items, hip
 }
 
 // one launch of the narrow-counter K = 8 kernel: counter width, window class (<= 2048 / <= 5120 bases), debug dump
-// (side: 4-bit counters with the side table for the period-4 max-mers - launches whose windows slide only)
+// (side: 4-bit counters with the side table for the period-4 max-mers)
 hipError_t launch_narrow(int kmax, int bits, bool small_w, bool debug, const ScanParams& P, int num_cu, int64_t work_items, hipStream_t st,
                          bool sample = false, bool side = false) {
     const bool slides = P.slide_pp > 0 && P.in_list == nullptr;        // (else: the instantiation without the ring, ROLE bit 1)
-    if (sample) {           // the 1/16 sample of the adaptive width: 4-bit counters, its own name in kernel statistics; where the
-                            // windows slide it runs the side-table form and counts what the plain form would have handed on as well
+    if (sample) {           // the sample of the adaptive width: 4-bit counters, its own name in kernel statistics; it runs the
+                            // side-table form and counts what the plain form would have handed on as well
         if (small_w) return slides ? launch_scan8<8, 256, 8, 4, 64, 3, false, 1, true>(P, num_cu, work_items, st)
-                                   : launch_scan8<8, 256, 8, 4, 64, 3, false, 3>(P, num_cu, work_items, st);
+                                   : launch_scan8<8, 256, 8, 4, 64, 3, false, 3, true>(P, num_cu, work_items, st);
         return slides ? launch_scan8<8, 256, 20, 4, 64, 3, false, 1, true>(P, num_cu, work_items, st)
-                      : launch_scan8<8, 256, 20, 4, 64, 3, false, 3>(P, num_cu, work_items, st);
+                      : launch_scan8<8, 256, 20, 4, 64, 3, false, 3, true>(P, num_cu, work_items, st);
     }
-    if (side && slides && bits == 4 && kmax == 8 && !debug) {
-        if (small_w) return launch_scan8<8, 256, 8, 4, 64, 3, false, 0, true>(P, num_cu, work_items, st);
-        return launch_scan8<8, 256, 20, 4, 64, 3, false, 0, true>(P, num_cu, work_items, st);
+    if (side && P.in_list == nullptr && bits == 4 && kmax == 8 && !debug) {
+        if (small_w) return slides ? launch_scan8<8, 256, 8, 4, 64, 3, false, 0, true>(P, num_cu, work_items, st)
+                                   : launch_scan8<8, 256, 8, 4, 64, 3, false, 2, true>(P, num_cu, work_items, st);
+        return slides ? launch_scan8<8, 256, 20, 4, 64, 3, false, 0, true>(P, num_cu, work_items, st)
+                      : launch_scan8<8, 256, 20, 4, 64, 3, false, 2, true>(P, num_cu, work_items, st);
     }
 #define FRISK_L7(K_, ITS_, DBG_) return launch_scan8<K_, 256, ITS_, 8, 64, FRISK_K7_WPS, DBG_>(P, num_cu, work_items, st)
     if (kmax == 7) {        // K = 6, 7: the 8-bit table is 16 / 4 KiB - registers, not LDS, bound the workgroups per CU
@@ -1356,11 +1358,14 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             P.ig_ring = c->d_ig_ring.p;
         }
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
+        // (the sample of the adaptive width: every 16th chunk, every 32nd of a long scan - a short launch runs at two thirds of a long
+        //  one's rate, tools/exp/launch_size.py, and 12 000 windows tell the shares as well as 25 000)
+        if (nchunks >= 64 * 32) P.sel_mod = 32;
         // chunks dealt by counters (scan8_kernel.h) where a chunk is long enough to pay for the exchange: a short scan keeps the static deal
         const bool dealt = chunk8 >= 4;
         int bulk = (width == 4 && narrow8) ? 4 : 8;
         bool side = false;              // 4-bit bulk with the side table (scan8_kernel.h, SIDE)
-        const bool side_ok = narrow8 && !debug && P.slide_pp > 0;
+        const bool side_ok = narrow8 && !debug;
         int sel_mode = 0;
         frisk_ctx::Batch& RB = c->b();
         const bool hinted = RB.width_hint != 0 && RB.hint_w == w && RB.hint_inc == inc;

@@ -49,8 +49,8 @@ enum {
                                         to the 8- and 16-bit forms (a short scan otherwise starts at 8 bits; a long one samples first).
                                         Results are the same bits. */
 #define FRISK_SCAN_SIDE4       1024u /* K = 8: as FRISK_SCAN_BITS4, with the side table for the max-mers of period <= 4 (poly-A, (CA)n, (AAAT)n
-                                        ...) beside the 4-bit counters where the windows slide - the form a long scan of repeat-rich
-                                        sequence picks by itself.  Results are the same bits. */
+                                        ...) beside the 4-bit counters - the form a long scan of repeat-rich sequence picks by itself.
+                                        Results are the same bits. */
 
 /* per-row status bits written to `status` by frisk_scan */
 #define FRISK_ROW_KEPT        1u      /* window passed the < 30 % non-ACGT filter (L237-241)          */

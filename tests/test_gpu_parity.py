@@ -523,19 +523,21 @@ def _genome_with_repeats(n, every, units=(b"A", b"T", b"CA", b"TG", b"AAT", b"GA
     return [s.tobytes()]
 
 
-@pytest.mark.parametrize("every,units,expect_bulk,expect_side", [
-    (60000, None, 4, False), (9000, None, 8, False), (9000, (b"A", b"T", b"CA", b"TG", b"GATA", b"AAAT"), 4, True)])
-def test_adaptive_counter_width_and_handover(every, units, expect_bulk, expect_side):
+@pytest.mark.parametrize("every,units,lens,expect_bulk,expect_side", [
+    (60000, None, None, 4, False), (9000, None, None, 4, True),
+    (3000, (b"AAT", b"CAG", b"TTAGGG", b"TTCCG", b"AAAAT"), (60, 90, 150, 900), 8, False),
+    (9000, (b"A", b"T", b"CA", b"TG", b"GATA", b"AAAT"), (24, 40, 60, 90, 150, 700), 4, True)])
+def test_adaptive_counter_width_and_handover(every, units, lens, expect_bulk, expect_side):
     """The default K = 8 kernel counts max-mers in 4- or 8-bit counters (scan8_kernel.h) and hands windows with a more
     frequent max-mer to the next wider form: 4-bit -> 8-bit -> 16-bit.  A 12 Mb genome with microsatellites and poly-A
     runs (a few of them longer than 8-bit counters hold) sprinkled in: every row must still equal the compiled oracle's,
     the hand-over lists must have been used, and the sample must have picked the expected form for the bulk: plain 4-bit
-    counters where repeats are sparse, 8-bit counters where they are dense and many of them of periods 3 or 6 or longer than
-    255 copies, 4-bit counters with the side table for max-mers of period <= 4 where dense repeats are mostly of that kind."""
+    counters where repeats are sparse, 4-bit counters with the side table for max-mers of period <= 4 where simple repeats are
+    dense, 8-bit counters where the dense repeats are of periods 3, 5 and 6, which the side table does not hold."""
     from oracle import frisk_oracle_c as OC
     from frisk_amd import _ffi
-    # (the side-table form exists for launches whose windows slide: scans of 12 288+ windows on this GPU)
-    seqs = _genome_with_repeats(12_000_000, every) if units is None else _genome_with_repeats(14_000_000, every, units, (24, 40, 60, 90, 150, 700))
+    # (14 Mb: a scan of 12 288+ windows goes in chunks, and the tables slide inside a chunk; 12 Mb: window by window)
+    seqs = _genome_with_repeats(12_000_000, every) if units is None else _genome_with_repeats(14_000_000 if expect_side else 12_000_000, every, units, lens)
     with make_engine(1, 8) as e:
         e.load(seqs)
         e.profile_reset(); e.profile_add(); e.profile_finalize()
