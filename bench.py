@@ -18,7 +18,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     - HBM roofline of the dominant kernel (scan): algorithmic bytes / HIP-event kernel time; `traffic`
                  and the `binding` block (what actually binds: VALU issue, LDS, waits) come from rocprofv3 PMC passes
                  of the same workload collected OFFLINE and committed under profiles/ (named in the line)
-  cold         - the FIRST step on a freshly resident batch (the adaptive counter width's 1/16 sample and its host sync are
+  cold         - the FIRST step on a freshly resident batch (the adaptive counter width's sample and its host sync are
                  paid there; the timed steps of `value` rescan a resident batch and reuse the sample's verdict)
   strong       - the WHOLE C5 shape (3.29 Gb, 3.06 M rows) as one job split over the N ranks (N = 1: all of it on one GPU):
                  the strong-scaling anchor beside the weak-scaling `value`
@@ -208,7 +208,7 @@ def timed_steps(step, fence, warmup, steps):
 
 def cold_step(eng, synth_args, step, fence):
     """One step on a batch that has just become resident (re-generated: any per-batch state of the library is gone): the
-    adaptive counter width runs its 1/16 sample, with a host synchronisation, inside this step."""
+    adaptive counter width runs its sample, with a host synchronisation, inside this step."""
     lens, kw = synth_args
     eng.synth(lens, **kw)
     fence()
@@ -397,7 +397,7 @@ def main(argv=None):
         few = max(2, min(opts.steps, 10))
         cold_ms, cold_scan_ms, _ = cold_step(eng, (lens, shard_kw), step, fence)
         cold = {"cold_first_step_ms": cold_ms, "cold_first_scan_kernel_ms": cold_scan_ms,
-                "note": "first step on a batch that has just become resident: includes the 1/16 sample of the adaptive counter "
+                "note": "first step on a batch that has just become resident: includes the sample (every 32nd chunk) of the adaptive counter "
                         "width and its host synchronisation; the steps behind `value` reuse the sample's verdict"}
         strong = strong_block(eng, dist, torch, rank, world, red_dev, fence, few)
         if world == 1:
@@ -448,6 +448,9 @@ def main(argv=None):
             "gbases_per_s": bases_all / (elapsed / opts.steps) / 1e9,
             "windowed_gbases_per_s": rows_all * W / (elapsed / opts.steps) / 1e9,      # rows x w: bases looked at, overlap counted
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
+            # (the timed steps one by one: the GPU's clocks are still rising through the first steps behind the input generator's
+            #  small launches - the first scan of a fresh batch is 0.85 ms slower than the third even without the sample)
+            "scan_kernel_ms_first_min_last": [scan_ms[0], min(scan_ms), scan_ms[-1]],
             "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
             "scan_counter_width": {"bulk_bits": width, "side_table_for_period4_maxmers": side_table, "windows_handed_to_8bit": handed8,
                                    "windows_handed_to_16bit": handed16},
