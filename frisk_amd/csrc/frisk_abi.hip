@@ -118,6 +118,7 @@ struct frisk_ctx {
     DevBuf<int64_t> d_raw, d_cnt, d_sym;
     DevBuf<double> d_ig, d_logtab, d_logtab64, d_logtab32, d_rctab;
     DevBuf<int64_t> d_ovf_list, d_ovf_list2;   // windows handed from 4-bit to 8-bit counters, and from there to the 16-bit form
+    uint64_t ig_gen = 1, ring_gen = 0;         // the genome table's generation, and the one whose copy heads d_ig_ring
     DevBuf<double> d_ig_ring;                  // scan8_kernel: per-workgroup ring of genome-side values by position (80 KB each at 20 positions per lane)
     DevBuf<unsigned int> d_ovf_count;          // per row segment 32 counters: [0], [1] the lists' lengths, [8..15] the bulk launch's chunk queues, [16] the 8-bit launch's
     int64_t scan_stat[5] = {0, 0, 0, 0, 0};    // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16, row segments,
@@ -378,6 +379,7 @@ int build_genome_table(frisk_ctx* c) {
     genome_ivom_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(c->d_sym.p, c->kmin, c->kmax, c->d_meta.p, c->d_ig.p);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(c->h_meta, c->d_meta.p, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    ++c->ig_gen;                    // (the copy of the table that heads the scan's ring buffer is stale)
     c->profile_final = true;        // in stream order: everything that follows on the context's stream sees the table
     return FRISK_OK;
 }
@@ -1353,8 +1355,12 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         // instantiations with the ring read it: launches whose windows slide, and the debug form
         if (narrow8 && (P.slide_pp > 0 || debug)) {
             const size_t slices = size_t(std::min<int64_t>(std::max<int64_t>((n + chunk8 - 1) / chunk8, 1), int64_t(c->num_cu) * 4));
+            const double* had = c->d_ig_ring.p;
             HIPC(c, c->d_ig_ring.reserve(nk + slices * 20 * FRISK8_RING_COLS));
-            HIPC(c, hipMemcpyAsync(c->d_ig_ring.p, c->d_ig.p, nk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            if (c->d_ig_ring.p != had || c->ring_gen != c->ig_gen) {        // (once per genome table, not once per scan)
+                HIPC(c, hipMemcpyAsync(c->d_ig_ring.p, c->d_ig.p, nk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                c->ring_gen = c->ig_gen;
+            }
             P.ig_ring = c->d_ig_ring.p;
         }
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     auto clear_small = [&]() {
         for (uint32_t i = tid0; i < L::small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
     };
+    // (a launch over a hand-over list finds it empty nearly always: nothing to set up)
+    if (P.in_list != nullptr && *P.in_count == 0u) return;
 #if FRISK8_PRIO
     __builtin_amdgcn_s_setprio(FRISK8_PRIO);
 #endif

@@ -400,6 +400,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void scan_kernel(const Sca
     const int lv = P.lv;                                // recursion shared up to this order (0: not shared)
     const int kshift = 16 - 2 * kmax;
 
+    // (a launch over a hand-over list finds it empty nearly always: nothing to set up)
+    if (P.in_list != nullptr && *P.in_count == 0u) return;
     // one-time clear of the histograms and counters
     if (K8) for (int i = tid; i < int(L.t8_bytes / 16); i += NT) reinterpret_cast<uint4*>(t8)[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tid; i < L.small_bytes / 16; i += NT) reinterpret_cast<uint4*>(small32)[i] = make_uint4(0, 0, 0, 0);
