@@ -251,14 +251,18 @@ class Engine:
             raw, stream = C.c_void_p(), C.c_void_p()
             self._check(self._lib.frisk_profile_device_view(self._ctx, C.byref(raw), C.byref(stream)))
 
-            class _View:
-                __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(raw.value), False), "version": 2}
-            dev = torch.device("cuda", self.device)
-            t = torch.as_tensor(_View(), device=dev)
-            ext = torch.cuda.ExternalStream(int(stream.value or 0), device=dev)
+            # (the tensor view and the stream wrapper are kept from step to step: the buffer and the stream belong to the context)
+            key = (int(raw.value), int(stream.value or 0), n)
+            kept = getattr(self, "_allreduce_keep", None)
+            if kept is None or kept[0] != key:
+                class _View:
+                    __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (key[0], False), "version": 2}
+                dev = torch.device("cuda", self.device)
+                kept = (key, torch.as_tensor(_View(), device=dev), torch.cuda.ExternalStream(key[1], device=dev))
+                self._allreduce_keep = kept
+            _, t, ext = kept
             with torch.cuda.stream(ext):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            self._allreduce_keep = (t, ext)
         else:
             from .distributed import allreduce_raw_host
             self.profile_set_raw(allreduce_raw_host(self.profile_raw(), group))
