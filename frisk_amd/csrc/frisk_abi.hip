@@ -1364,9 +1364,10 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             P.ig_ring = c->d_ig_ring.p;
         }
         const int64_t nchunks = (n + chunk8 - 1) / chunk8;
-        // (the sample of the adaptive width: every 16th chunk, every 32nd of a long scan - a short launch runs at two thirds of a long
-        //  one's rate, tools/exp/launch_size.py, and 12 000 windows tell the shares as well as 25 000)
-        if (nchunks >= 64 * 32) P.sel_mod = 32;
+        // (the sample of the adaptive width: every 16th chunk, every 32nd or fewer of a long scan - a short launch runs at two thirds
+        //  of a long one's rate, tools/exp/launch_size.py, and 12 000 windows tell the shares as well as 25 000
+        //  ... and no more chunks than the launch has workgroups - one round: a second chunk for a few of them doubled its time)
+        if (nchunks >= 64 * 32) P.sel_mod = int32_t(std::max<int64_t>(32, (nchunks + int64_t(c->num_cu) * 3 - 1) / (int64_t(c->num_cu) * 3)));
         // chunks dealt by counters (scan8_kernel.h) where a chunk is long enough to pay for the exchange: a short scan keeps the static deal
         const bool dealt = chunk8 >= 4;
         int bulk = (width == 4 && narrow8) ? 4 : 8;
