@@ -512,9 +512,22 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     };
                     return (squeeze(uint32_t(acode >> 32)) << 16) | squeeze(uint32_t(acode));
                 };
-                auto tally = [&](uint32_t sel) {                     // sel: the lane's positions to count
-                    cAll = wave_sum_u32(uint32_t(__popc(sel)));
-                    cGC = wave_sum_u32(uint32_t(__popc(sel & gc_plane())));
+                // (`ntop_`: the lane's max-mer starts.  The three counts of a lane are at most ITS each, so the sums over a row of 16
+                //  lanes fit ten bits and travel through ONE butterfly; the squeeze behind the G + C plane is needed only where some
+                //  lane of the wave holds an invalid or soft-masked base: elsewhere the selected positions are the lane's first
+                //  popc(actm), and their G + C count is one masked popcount of the codes' high bits.)
+                auto tally = [&](uint32_t sel, uint32_t ntop_) {     // sel: the lane's positions to count
+                    static_assert(ITS <= 31, "three ten-bit fields: a lane's counts below 32, a pair of rows' sums below 1024");
+                    uint32_t gcl;
+                    if (__any(sel != actm)) gcl = uint32_t(__popc(sel & gc_plane()));
+                    else gcl = uint32_t(__popcll(acode & 0xAAAAAAAAAAAAAAAAull & ~(0xFFFFFFFFFFFFFFFFull >> (2 * __popc(actm)))));
+                    uint32_t x = uint32_t(__popc(sel)) | (gcl << 10) | (ntop_ << 20);
+                    x = dpp_addu<0xB1>(x); x = dpp_addu<0x4E>(x); x = dpp_addu<0x141>(x); x = dpp_addu<0x140>(x);     // (as wave_sum_u32)
+                    const uint32_t a = uint32_t(__builtin_amdgcn_readlane(int(x), 0) + __builtin_amdgcn_readlane(int(x), 16));
+                    const uint32_t b = uint32_t(__builtin_amdgcn_readlane(int(x), 32) + __builtin_amdgcn_readlane(int(x), 48));
+                    cAll = (a & 1023u) + (b & 1023u);
+                    cGC = ((a >> 10) & 1023u) + ((b >> 10) & 1023u);
+                    nvalid = (a >> 20) + (b >> 20);
                 };
                 // a position next to an invalid base or the window's end: the longest valid word there has 0..K-1 bases.
                 // Orders <= K-3 count it in the small tables (at order min(run, K-3): lower orders follow by
@@ -579,12 +592,9 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                         }
                     }
                 }
-                const uint32_t ntop = __popc(fullm);
-#pragma unroll
-                for (int b = 0; (1 << b) <= ITS; ++b) nvalid += uint32_t(__popcll(__ballot((ntop >> b) & 1u))) << b;
                 // (the order-1 table could give these two when kmin = 1, but only after the marginalisation - which now runs
                 //  inside stage 3, where the window constants made from them are already needed)
-                tally(actm & vld & ~alow);
+                tally(actm & vld & ~alow, uint32_t(__popc(fullm)));
                 {   // the code of one max-mer of this window, any: positions that start none score it with weight 0, so that
                     // every lane computes finite values and no term needs masking (which wave's wins does not matter)
                     const unsigned long long have = __ballot(fullm != 0u);
