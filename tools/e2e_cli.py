@@ -25,11 +25,13 @@ elif shape == "C5shard":
 else:
     lens, nfrac = [n for r in range(8) for n in synth.c5_shard_lens(8, r)], 0.07
 
-fa = os.path.join(work, shape + ".fa")
+fa = os.path.join(work, shape + ("_repeats" if os.environ.get("E2E_REPEATS") else "") + ".fa")
 t0 = time.time()
 if not os.path.exists(fa):
     with Engine(1, 4) as e, open(fa, "wb") as fh:
-        e.synth(lens, seed=0xE2E, island_frac=0.02, n_frac=nfrac, lower_frac=0.02)
+        # (E2E_REPEATS: simple repeats per kb, frisk_amd/synth.py - 0.35 is the bench's `realistic` shape: the CLI's scan then samples, and takes
+        #  the 4-bit form with the side table)
+        e.synth(lens, seed=0xE2E, island_frac=0.02, n_frac=nfrac, lower_frac=0.02, repeats_per_kb=float(os.environ.get("E2E_REPEATS", "0")))
         for i, n in enumerate(lens):
             s = np.frombuffer(e.read_seq(i), dtype=np.uint8)
             fh.write(b">scaffold_%d synthetic\n" % i)
