@@ -301,6 +301,8 @@ def main(argv=None):
                     help="scale every scaffold length of the shard (testing only; 1.0 = the named workload)")
     ap.add_argument("--cpu-windows", type=int, default=150, help="windows in the CPU-baseline sample, ~0.1 s each (0 = skip)")
     ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive measurements")
+    ap.add_argument("--repeats", type=float, default=0.0,
+                    help="simple repeats per kb in the synthetic shard (profiling runs of the `realistic` shape: 0.35; the headline metric is 0)")
     ap.add_argument("--no-extra", action="store_true", help="skip the cold / strong / realistic blocks (profiling runs)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (gloo, no GPU): proves the N-rank launch path; rank 0 prints {dry_run, world}")
@@ -349,7 +351,7 @@ def main(argv=None):
     from frisk_amd import Engine, synth
     lens = [max(1, int(x * opts.shard_scale)) for x in synth.c5_shard_lens(8, rank % 8)]
     eng = Engine(KMIN, KMAX, device=local_rank)
-    eng.synth(lens, seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0)
+    eng.synth(lens, seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0, repeats_per_kb=opts.repeats)
     n_cand = eng.scan_plan(W, INC)
     total_bases = sum(lens)
 
@@ -390,7 +392,7 @@ def main(argv=None):
     else:
         rows_all, bases_all, cand_all = float(rows), float(total_bases), float(n_cand)
 
-    shard_kw = dict(seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0)
+    shard_kw = dict(seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0, repeats_per_kb=opts.repeats)
     cold = strong = None
     realistic = []
     if not opts.no_extra:
@@ -444,7 +446,7 @@ def main(argv=None):
                                    "one 1/8 LPT shard per GPU (N=8 is the full 3.1 Gb job), k=1..8 w=5000 i=1000; "
                                    "step = genome profile + all-reduce + window scan, inputs packed and resident in HBM",
                        "bases_per_gpu": total_bases, "candidate_windows_per_gpu": n_cand, "rows_per_gpu_rank0": rows,
-                       "shard_scale": opts.shard_scale},
+                       "shard_scale": opts.shard_scale, **({"simple_repeats_per_kb": opts.repeats} if opts.repeats else {})},
             "gbases_per_s": bases_all / (elapsed / opts.steps) / 1e9,
             "windowed_gbases_per_s": rows_all * W / (elapsed / opts.steps) / 1e9,      # rows x w: bases looked at, overlap counted
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
