@@ -342,14 +342,21 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     // windows overlap - go through the same L2, as with the static deal; a workgroup whose XCD has run dry takes from the
     // next one's.  Thread 0 asks for the chunk after this one before it starts on this one, so the round trip of the atomic
     // hides behind a chunk's work.
+    // The pointers that are used once per window or per chunk, by one thread - the row's output columns, the hand-over list, the chunk
+    // queues, the descriptors - come from the kernel-argument segment where they are used, through a pointer the optimiser cannot see
+    // through (laundered per chunk and per window): held in scalar registers across the window loop, these sixteen pointers were
+    // sixteen pairs parked in VGPR lanes and read back every window (120 -> 89 spilled scalars, 334 -> 186 v_readlane in the loop).
+    typedef const __attribute__((address_space(4))) ScanParams* KernargView;
+    KernargView Pk = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t* next_q = reinterpret_cast<uint32_t*>(scratch);         // (the waves' partial sums live here at the END of a window)
-    const bool dealt = P.queue != nullptr;
+    const bool dealt = Pk->queue != nullptr;
     const uint32_t NQ = dealt ? uint32_t(P.queue_n) : 1u;
     const uint32_t myq = blockIdx.x % NQ;
     uint32_t dry = 0, ahead = 0;                                     // (thread 0) queues found empty so far; the index asked for ahead
-    if (dealt && tid0 == 0) ahead = atomicAdd(&P.queue[myq], 1u);
+    if (dealt && tid0 == 0) ahead = atomicAdd(&Pk->queue[myq], 1u);
     for (int64_t qs = v;; qs += G) {
         int64_t q = qs;
+        asm volatile("" : "+s"(Pk));
         if (dealt) {
             if (tid0 == 0) {
                 uint32_t got = 0xFFFFFFFFu;
@@ -357,10 +364,10 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     const uint32_t j = (myq + dry) % NQ;
                     const int64_t b = nchunks * j / NQ, len = nchunks * (j + 1) / NQ - b;
                     if (int64_t(ahead) < len) { got = uint32_t(b + ahead); break; }
-                    if (++dry < NQ) ahead = atomicAdd(&P.queue[(myq + dry) % NQ], 1u);
+                    if (++dry < NQ) ahead = atomicAdd(&Pk->queue[(myq + dry) % NQ], 1u);
                 }
                 *next_q = got;
-                if (got != 0xFFFFFFFFu) ahead = atomicAdd(&P.queue[(myq + dry) % NQ], 1u);
+                if (got != 0xFFFFFFFFu) ahead = atomicAdd(&Pk->queue[(myq + dry) % NQ], 1u);
             }
             __syncthreads();
             const uint32_t got = uint32_t(__builtin_amdgcn_readfirstlane(int(*next_q)));
@@ -375,15 +382,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
         const int64_t cb = listed ? q : P.c0 + qq * chunk;
         const int64_t ce = listed ? q + 1 : ((cb + chunk < P.c1) ? cb + chunk : P.c1);
         for (int64_t ci = cb; ci < ce; ++ci) {
-            const int64_t cand = listed ? P.in_list[ci] : ci;
+            const int64_t cand = listed ? Pk->in_list[ci] : ci;
             // ---- which scaffold / window is this candidate? (uniform; crawlGenome L194-251)
             if (cand < d.cand0 || cand >= d.cand0 + d.ncand) {
                 int lo = 0, hi = P.n_desc - 1;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
-                    if (P.descs[mid].cand0 <= cand) lo = mid; else hi = mid - 1;
+                    if (Pk->descs[mid].cand0 <= cand) lo = mid; else hi = mid - 1;
                 }
-                d = P.descs[lo];
+                d = Pk->descs[lo];
                 dsi = lo;
                 // (into scalar registers: the descriptor is the same for every lane, but a plain global load leaves it in vector
                 //  registers, and the window geometry below - 64-bit multiplies and compares per window - then runs on the VALU)
@@ -399,6 +406,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // dozens of spilled scalars) out of the window loop and keeps them alive across all stages.
             int tid = tid0, kmin = kmin0;
             asm volatile("" : "+v"(tid), "+s"(kmin));
+            asm volatile("" : "+s"(Pk));            // (kernel arguments used once per window: re-read from their segment, see Pk)
 #ifdef FRISK_STAMPS
             ++stamp_win;
 #endif
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 // a rescued small scaffold (--scaffoldsAll, L211-221: up to 1.75 w bases) longer than this kernel's lanes cover:
                 // straight to the wider forms - per WINDOW, so that which kernel scores a window never depends on what else
                 // is resident (a rank of a multi-GPU job sees other scaffolds than the one-GPU run)
-                if (tid == 0) { const unsigned int slot = atomicAdd(P.out_count, 1u); P.out_list[slot] = cand; }
+                if (tid == 0) { const unsigned int slot = atomicAdd(Pk->out_count, 1u); Pk->out_list[slot] = cand; }
                 continue;
             }
             uint32_t* misc = misc_base + parity * FRISK8_SLOTS;
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             auto hand_over = [&]() {
                 if (!slide_next) clear_t8();
                 clear_small();
-                if (tid == 0) { const unsigned int slot = atomicAdd(P.out_count, 1u); P.out_list[slot] = cand; }
+                if (tid == 0) { const unsigned int slot = atomicAdd(Pk->out_count, 1u); Pk->out_list[slot] = cand; }
                 __syncthreads();
             };
             if (wrapped) { hand_over(); continue; }
@@ -697,11 +705,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 if (!slide_next) { if (CLEAR_ALL) clear_t8(); else zero_own(); }
                 clear_small();
                 if (tid == 0) {
-                    P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop;
-                    P.status[row] = status;
+                    Pk->seq_index[row] = dsi; Pk->start[row] = rep_start; Pk->stop[row] = rep_stop;
+                    Pk->status[row] = status;
                     const double qnan = __longlong_as_double(0x7FF8000000000000LL);
-                    P.kld[row] = qnan; P.gc[row] = qnan;
-                    if (P.flags & 1u) { P.pi[row] = qnan; P.si[row] = qnan; P.cri[row] = qnan; }
+                    Pk->kld[row] = qnan; Pk->gc[row] = qnan;
+                    if (P.flags & 1u) { Pk->pi[row] = qnan; Pk->si[row] = qnan; Pk->cri[row] = qnan; }
                     if (DEBUG && P.dbg_meta) {      // (dropped rows are not compared; keep the dump well defined)
                         P.dbg_meta[row * 3 + 0] = n; P.dbg_meta[row * 3 + 1] = 0; P.dbg_meta[row * 3 + 2] = nn;
                     }
@@ -709,7 +717,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 __syncthreads();
                 continue;
             }
-            if (tid == 0) { P.seq_index[row] = dsi; P.start[row] = rep_start; P.stop[row] = rep_stop; }
+            if (tid == 0) { Pk->seq_index[row] = dsi; Pk->start[row] = rep_start; Pk->stop[row] = rep_stop; }
 
             // The orphan list: its first four entries in scalar registers.  A run-(K-1) entry is its (K-1)-mer; a run-(K-2) entry
             // has bit 15 set and holds its (K-2)-mer << 2.  o6[k] = the (K-2)-mer of entry k (both kinds count towards c6), o7[k] =
@@ -1094,7 +1102,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             }
             // (the sample of the adaptive width: windows that reach the scoring loop, and those among them that a plain 4-bit table would
             //  have handed on - a side count of 16+)
-            if (SIDE && (ROLE & 1) && tid == 0) { atomicAdd(P.out_count + 3, 1u); if (pmask_raw >> 31) atomicAdd(P.out_count + 2, 1u); }
+            if (SIDE && (ROLE & 1) && tid == 0) { atomicAdd(Pk->out_count + 3, 1u); if (pmask_raw >> 31) atomicAdd(Pk->out_count + 2, 1u); }
             load_orphans(placed);
 
             if (DEBUG && P.dbg_counts) {
@@ -1113,15 +1121,15 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             if (nvalid_top > 0 && S >= kmin - 1 && S <= K - 1) status |= ROW_ZERO_WEIGHT;          // zero divisor on the window side
             status |= ROW_KEPT;
             if (tid == 0) {
-                P.gc[row] = __longlong_as_double((long long)((uint64_t(uint32_t(S)) << 32) | upGC));
+                Pk->gc[row] = __longlong_as_double((long long)((uint64_t(uint32_t(S)) << 32) | upGC));
                 if (P.flags & 1u) {             // RIP indices (L474-495); codes: AT=1 TA=4 TG=6 GT=9 CA=12 AC=3
                     const double qnan = __longlong_as_double(0x7FF8000000000000LL);
                     const uint32_t AT = count(2, 1), TA = count(2, 4), TG = count(2, 6), GT = count(2, 9), CA = count(2, 12), AC = count(2, 3);
                     const double pi = AT > 0 ? double(TA) / double(AT) : qnan;
                     const double si = (AC + GT) > 0 ? double(CA + TG) / double(AC + GT) : qnan;
-                    P.pi[row] = pi;
-                    P.si[row] = si;
-                    P.cri[row] = (pi == 0.0 || si == 0.0) ? qnan : pi - si;                     // "if PI and SI" (L491)
+                    Pk->pi[row] = pi;
+                    Pk->si[row] = si;
+                    Pk->cri[row] = (pi == 0.0 || si == 0.0) ? qnan : pi - si;                     // "if PI and SI" (L491)
                 }
             }
 
@@ -1349,10 +1357,10 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             if (tid == 0) {
                 double a = 0.0, b = 0.0, c = 0.0;
                 for (int w = 0; w < NW; ++w) { a += scratch[3 * w]; b += scratch[3 * w + 1]; c += scratch[3 * w + 2]; }
-                P.status[row] = status;
-                P.sw[row] = a;
-                P.sg[row] = b;
-                P.kld[row] = c;                             // T; finish_rows_kernel turns (T, Sw, Sg) into the KLD
+                Pk->status[row] = status;
+                Pk->sw[row] = a;
+                Pk->sg[row] = b;
+                Pk->kld[row] = c;                             // T; finish_rows_kernel turns (T, Sw, Sg) into the KLD
             }
             STAMP(8)
             __syncthreads();
