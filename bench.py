@@ -463,7 +463,7 @@ def main(argv=None):
                                          "round 3 almost all of it is the per-workgroup ring that carries genome-side values from window to window "
                                          "(61 MB in all: beyond L2, inside the 256 MB Infinity Cache) - traded for a 3.5 x cut of the L2 -> L1 line "
                                          "traffic that bound the kernel (`l2_gather`)",
-                         "kernel": "scan8_kernel: the two bulk launches of a scan (15/16 of the rows, and the last 1/16 on a second stream while the first rows go to the host) + its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them",
+                         "kernel": "scan8_kernel: the two bulk launches of a scan (about 15/16 of the rows, and the rest - whole rounds of the launch's workgroups - on a second stream while the first rows go to the host) + its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them",
                          "algorithmic_bytes_per_launch": b_alg,
                          "bulk_launches_per_scan": row_segments,
                          "duration_ms": scan_avg,
