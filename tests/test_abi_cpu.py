@@ -32,6 +32,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.frisk_supported(1, 8, 70000) == 1 and lib.frisk_supported(1, 8, 2 ** 31) == 0 and lib.frisk_supported(1, 8, 0) == 0
 
 
+def test_header_constants_equal_the_ctypes_side():
+    """Flags, row status bits and error codes of include/frisk_hip.h against frisk_amd/_ffi.py: a drift would silently change
+    which kernel form a scan takes (FRISK_SCAN_BITS4 / FRISK_SCAN_SIDE4 are test hooks) or how a row is read."""
+    from frisk_amd import _ffi
+    text = open(os.path.join(REPO, "include", "frisk_hip.h")).read()
+    defines = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+FRISK_(SCAN_[A-Z0-9_]+|ROW_[A-Z0-9_]+)\s+(\d+)u", text)}
+    assert len(defines) >= 9, defines
+    for name, value in defines.items():
+        assert getattr(_ffi, name) == value, name
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"FRISK_(OK|E_[A-Z_]+)\s*=\s*(-?\d+)", text)}
+    assert len(enums) == 7, enums
+    for name, value in enums.items():
+        assert getattr(_ffi, name) == value, name
+    flags = [v for k, v in defines.items() if k.startswith("SCAN_")]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)          # distinct single bits
+
+
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
     from frisk_amd import _ffi
     monkeypatch.setattr(_ffi, "_lib", None)
