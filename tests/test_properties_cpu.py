@@ -83,3 +83,43 @@ def test_window_enumeration_matches_reference_shape(size, w, inc):
                 assert (a, b, start, stop) == (j, j + w, j + 1, j + w)
             else:
                 assert (b, start, stop) == (size, size - w, size) and a == max(0, 2 * size - w if size < w else size - w)
+
+
+def test_side_table_index_arithmetic_of_the_scan_kernel():
+    """The identities scan8_kernel.h's SIDE form rests on (csrc/scan8_kernel.h, "SIDE"), by brute force over all 4^8 max-mers:
+    with t = (c ^ c >> 8) & 0xFF the period-4 max-mers (y)(y) below the (K-2)-mer / (K-1)-mer of c, and c itself, are exactly
+    {(c >> 8)(c >> 8)} where t < 16 / t < 4 / t == 0 and none otherwise; the orphan placement's exclusions name exactly the
+    period-4 child of a (K-1)-mer and the (K-1)-mers with a period-4 child below a (K-2)-mer; the side count fits the bits
+    above the prefix weight."""
+    import numpy as np
+    c = np.arange(1 << 16, dtype=np.int64)
+    period4 = (c >> 8) == (c & 0xFF)                                  # x0..x3 == x4..x7
+    t = (c ^ (c >> 8)) & 0xFF
+    assert np.array_equal(period4, t == 0) and period4.sum() == 256
+    side_code = ((c >> 8) << 8) | (c >> 8)                           # (y)(y), y = the code's first four bases
+    # below the (K-2)-mer c >> 4: its sixteen children; below the (K-1)-mer c >> 2: its four
+    for shift, bound in ((4, 16), (2, 4)):
+        kids = ((c >> shift) << shift)[:, None] + np.arange(1 << shift)[None, :]
+        is_p4 = (kids >> 8) == (kids & 0xFF)
+        n_p4 = is_p4.sum(axis=1)
+        assert np.array_equal(n_p4, (t < bound).astype(np.int64))     # one where t < bound, none elsewhere
+        which = np.where(n_p4 == 1, (kids * is_p4).sum(axis=1), -1)
+        assert np.array_equal(which[t < bound], side_code[t < bound])
+    # orphan (K-1)-mer e (14 bits): its period-4 child, if any, is e << 2 | x3 and exists iff x4 x5 x6 == x0 x1 x2
+    e = np.arange(1 << 14, dtype=np.int64)
+    kids = (e << 2)[:, None] + np.arange(4)[None, :]
+    is_p4 = (kids >> 8) == (kids & 0xFF)
+    has = ((e ^ (e >> 8)) & 0x3F) == 0
+    assert np.array_equal(is_p4.any(axis=1), has)
+    assert np.array_equal(np.argmax(is_p4, axis=1)[has], ((e >> 6) & 3)[has])
+    # orphan (K-2)-mer q (12 bits): the (K-1)-mers q << 2 | b below it that hold a period-4 max-mer: b == x2, iff x4 x5 == x0 x1
+    q = np.arange(1 << 12, dtype=np.int64)
+    grand = (q << 4)[:, None] + np.arange(16)[None, :]
+    is_p4 = ((grand >> 8) == (grand & 0xFF)).reshape(len(q), 4, 4).any(axis=2)      # [q, b]
+    has = ((q ^ (q >> 8)) & 0xF) == 0
+    assert np.array_equal(is_p4.any(axis=1), has)
+    assert np.array_equal(np.argmax(is_p4, axis=1)[has], ((q >> 6) & 3)[has])
+    # the prefix weight of the orders <= K-3 (at most 5 120 positions per window) leaves nine bits: an 8-bit side count fits
+    assert 5120 * sum(4 ** x for x in range(1, 6)) < 1 << 23
+    # three workgroups per CU: LDS is handed out in pieces of 1 280 bytes, 128 of them per CU
+    assert 3 * -(-53376 // 1280) <= 128 and 3 * -(-49280 // 1280) <= 128 and 2 * -(-81920 // 1280) <= 128
