@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """bench.py - whole-job throughput of the frisk hot path on N MI355X (one process per GPU).
 
-A step = one pass of the hot path over the rank's resident synthetic shard:
+A step = one pass of the hot path over the rank's resident synthetic assembly:
     phase A  profile_reset -> profile_add -> [ONE all-reduce of the raw profile over RCCL] -> finalize
     phase B  window scan of every candidate window (kernels + D2H of the result rows)
-with the packed scaffolds already resident in HBM when the timed region starts.
+with the packed scaffolds already resident in HBM when the timed region starts (`value`; the task's bench contract).
 
-Workload (config.workload): BASELINE.json's metric geometry k=1..8, w=5000, i=1000 on the C5 shape
-(GRCh38-like: 24 chromosome-scale + 400 small synthetic scaffolds, ~3.1 Gb, ~7 % N) split into 8
-shards by longest-processing-time bin packing; every rank owns ONE shard (~388 Mb, ~388 k candidate
-windows), so N = 8 is the full C5 job and N < 8 is the same per-GPU work (weak scaling).
+Workload (config.workload): BASELINE.json's metric geometry k=1..8, w=5000, i=1000 on the configuration the metric is quoted
+on - C5, the GRCh38-like shape (24 chromosome-scale + 400 small synthetic scaffolds, 3.29 Gb, ~7 % N, 3.28 M candidate windows):
+it fits one GPU (4.9 GB of 288), so N = 1 is the whole C5 job on one MI355X.  Weak scaling: every rank owns one assembly of
+that shape (its own seed), the genome profile is pooled over all ranks by the one all-reduce.  `strong` (N > 1) is the other
+reading of BASELINE's C5 line: ONE assembly split over the N ranks.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks
 (torch.distributed.run, 127.0.0.1) before anything touches the GPU and relays rank 0's line.
@@ -18,14 +19,14 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     - HBM roofline of the dominant kernel (scan): algorithmic bytes / HIP-event kernel time; `traffic`
                  and the `binding` block (what actually binds: VALU issue, LDS, waits) come from rocprofv3 PMC passes
                  of the same workload collected OFFLINE and committed under profiles/ (named in the line)
-  cold         - the FIRST step on a freshly resident batch (the adaptive counter width's sample and its host sync are
-                 paid there; the timed steps of `value` rescan a resident batch and reuse the sample's verdict)
-  strong       - the WHOLE C5 shape (3.29 Gb, 3.06 M rows) as one job split over the N ranks (N = 1: all of it on one GPU):
-                 the strong-scaling anchor beside the weak-scaling `value`
-  realistic    - the same shard with simple repeats at a primate-like density (poly-A/T tails, microsatellites), unmasked and
-                 soft-masked: the counter widths real assemblies take, first (cold) step included
-  upload       - the same job including host -> HBM: one job from page-locked ASCII, one from the
-                 0.5 B/base packed form, and the steady state with the next batch's upload overlapped (N = 1 only)
+  inclusive    - SURVEY.md 8(d)'s quantity: the SAME whole job from page-locked host memory, timed over H2D + profile + scan +
+                 D2H, cold (a fresh batch every time): the 0.25 B/base form (2-bit codes + run lists of the two masks, the
+                 codes streamed in pieces with phase A following them), beside the 0.5 B/base and the ASCII forms (N = 1 only)
+  cold         - the FIRST step on a freshly resident batch (the adaptive counter width's sample is paid there)
+  shard        - the 1/8 LPT shard of the C5 shape that rounds 1-3 reported as `value` (the per-GPU work of an 8-GPU C5 job)
+  strong       - N > 1: ONE C5 assembly split over the N ranks
+  realistic    - the shard with repeat content (simple repeats of period 1-6, satellite arrays), unmasked and soft-masked:
+                 the counter widths real assemblies take, first (cold) step included
   cpu_baseline - the reference-shaped Python oracle timed on one host core on a bounded sample
                  (+ cpu_baseline_numpy, cpu_baseline_c: the vectorised and the compiled multi-thread restatements)
 """
@@ -135,48 +136,61 @@ def cpu_baseline_c(engine, sym, meta, seq0_len, n_windows=60000):
                       "candidate windows of scaffold 0 (%d kept); %.2f s" % (n_windows, len(exp["kld"]), dt)}
 
 
-def upload_inclusive(eng, lens, step, fence, steps, rows):
-    """SURVEY.md 8d asks for windows/s over kernel + H2D/D2H.  The genome profile needs EVERY base before the first window
-    can be scored, so inside one job the upload cannot hide behind the scan; it can hide behind the previous job's.
-    Three figures, host buffers page-locked, same shard, same step():
-      single_job_ascii   stage(ASCII, 1 B/base) -> commit -> step          (latency of one job from host memory)
-      single_job_packed  stage(packed, 0.5 B/base) -> commit -> step       (the sequence-cache form)
-      pipelined_ascii    [stage(next) || step(resident)] -> commit, steady state (a stream of batches / jobs)"""
+def inclusive_block(eng, lens, step, fence, steps, rows, bases):
+    """windows/s = emitted rows / wall time of phase B's job from host memory - kernels + H2D + D2H, FASTA
+    parsing (and the host-side packing, which the parser's threads do) excluded.  The genome profile needs EVERY base before
+    the first window can be scored, so inside one job the scan cannot start before the upload ends; what CAN overlap is
+    phase A: the codes cross PCIe in pieces and profile_add follows the pieces.  Every timed job is cold: a fresh batch in the
+    other slot, the adaptive counter width sampled again.  Host buffers page-locked.  Three forms of the same job:
+      from_2bit    0.25 B/base codes + run lists of the two masks (frisk_pack_2bit -> frisk_seq_stage_2bit)   <- the figure
+      from_packed  0.5 B/base: codes + two dense bitmaps (frisk_seq_stage_packed)
+      from_ascii   1 B/base, packed on the device (frisk_seq_stage)"""
     import numpy as np
     total = sum(lens)
     big = eng.host_array("ascii", total)
     views, o = [], 0
-    for i, n in enumerate(lens):            # the synthetic shard back to the host once (not timed)
-        big[o:o + n] = np.frombuffer(eng.read_seq(i), dtype=np.uint8)
+    piece = 1 << 26
+    for i, n in enumerate(lens):            # the synthetic assembly back to the host once (not timed)
+        for a in range(0, n, piece):
+            m = min(piece, n - a)
+            big[o + a:o + a + m] = np.frombuffer(eng.read_seq(i, a, m), dtype=np.uint8)
         views.append(big[o:o + n])
         o += n
+    t0 = time.perf_counter()
+    codes2, inv_runs, low_runs, _ = eng.pack_2bit(views, pinned=True)
+    pack_s = time.perf_counter() - t0
     codes, inv, low = eng.export_packed(pinned=True)
     out = {}
 
-    def timed(body, label, nbytes):
+    def timed(body, label, nbytes, reps):
         body()                               # warm-up: allocates the second batch slot
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(reps):
             body()
         fence()
-        dt = (time.perf_counter() - t0) / steps
-        out[label] = {"windows_per_s": rows / dt, "ms_per_step": dt * 1e3, "pcie_bytes_per_step": nbytes}
+        dt = (time.perf_counter() - t0) / reps
+        out[label] = {"windows_per_s": rows / dt, "gbases_per_s": bases / dt / 1e9, "ms_per_job": dt * 1e3,
+                      "pcie_bytes_per_job": int(nbytes), "jobs_timed": reps}
 
-    def single_ascii():
-        eng.stage(views); eng.commit(); step()
+    def job_2bit():
+        eng.stage_2bit(codes2, inv_runs, low_runs, lens); eng.commit(); step()
 
-    def single_packed():
+    def job_packed():
         eng.stage_packed(codes, inv, low, lens); eng.commit(); step()
 
-    def pipelined():
-        eng.stage(views); step(); eng.commit()
+    def job_ascii():
+        eng.stage(views); eng.commit(); step()
 
-    timed(single_ascii, "single_job_ascii", total)
-    timed(single_packed, "single_job_packed", int(codes.nbytes + inv.nbytes + low.nbytes))
-    timed(pipelined, "pipelined_ascii", total)
-    out["note"] = ("host buffers page-locked; never part of `value`.  The profile needs all bases before the first window is "
-                   "scored, so a single job pays upload + scan; a stream of batches hides the upload behind the previous scan")
+    timed(job_2bit, "from_2bit", codes2.nbytes + inv_runs.nbytes + low_runs.nbytes, steps)
+    timed(job_packed, "from_packed", codes.nbytes + inv.nbytes + low.nbytes, max(2, steps // 2))
+    timed(job_ascii, "from_ascii", total, max(2, steps // 2))
+    out["value"] = out["from_2bit"]["windows_per_s"]
+    out["unit"] = "windows/s (emitted rows / wall time of H2D + profile + scan + D2H; every job cold)"
+    out["mask_runs"] = {"inv": int(inv_runs.shape[0]), "low": int(low_runs.shape[0])}
+    out["host_pack_s"] = pack_s
+    out["note"] = ("SURVEY.md 8(d)'s definition of windows/s; never `value` (the bench contract keeps `value` on inputs resident in HBM).  "
+                   "host_pack_s = frisk_pack_2bit over the whole assembly (ASCII -> 2 bits + run lists, host threads), part of parsing, not timed")
     return out
 
 def csrc_hash():
@@ -236,14 +250,35 @@ def shape_block(eng, lens, kw, step, fence, steps, label):
             "max_kld": float(np.nanmax(res.kld[res.kept])) if rows else None}
 
 
+def c5_lens():
+    """The whole C5 shape: the eight LPT shards one after the other (424 scaffolds, 3.29 Gb)."""
+    from frisk_amd import synth
+    return [n for r in range(8) for n in synth.c5_shard_lens(8, r)]
+
+
+def shard_block(eng, rank, make_step, fence, steps):
+    """The 1/8 LPT shard of the C5 shape (~410 Mb, ~410 k candidate windows) that rounds 1-3 reported as `value`: the per-GPU
+    work of an 8-GPU C5 job, and the size at which a scan's fixed costs show."""
+    from frisk_amd import synth
+    lens = synth.c5_shard_lens(8, rank % 8)
+    kw = dict(seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0)
+    step = make_step()
+    cold_ms, cold_scan_ms, _ = cold_step(eng, (lens, kw), step, fence)
+    dt, res, scan_ms = timed_steps(step, fence, 2, steps)
+    rows = int(res.kept.sum())
+    return {"workload": "one 1/8 LPT shard of the C5 shape, resident", "bases": sum(lens), "candidate_windows": len(res), "rows": rows,
+            "value": rows / dt, "unit": "windows/s", "ms_per_step": dt * 1e3, "scan_kernel_ms": scan_ms,
+            "scan_kernel_windows_per_s": len(res) / (scan_ms * 1e-3), "cold_first_step_ms": cold_ms,
+            "cold_first_scan_kernel_ms": cold_scan_ms}, lens
+
+
 def strong_block(eng, dist, torch, rank, world, red_dev, fence, steps):
     """The whole C5 shape as ONE job over the N ranks: every rank holds the packed assembly (4.9 GB of 288), counts the k-mers
     that start in its N-th of the positions, the raw profiles are summed by the one all-reduce, and every rank scores its N-th
     of the candidate windows (contiguous ranges in output order; rows stay on the rank, as in the weak steps).  N = 1 is the
     whole job on one GPU.  (The CLI's multi-GPU path shards the residency too - frisk_fasta_load_shard; here the point is the
     time of the job against N.)"""
-    from frisk_amd import synth
-    lens = [n for r in range(8) for n in synth.c5_shard_lens(8, r)]
+    lens = c5_lens()
     eng.synth(lens, seed=0xC5, island_frac=0.02, n_frac=0.07, lower_frac=0.0)
     n_cand = eng.scan_plan(W, INC)
     padded = eng.padded_len
@@ -298,9 +333,12 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shard-scale", type=float, default=1.0,
-                    help="scale every scaffold length of the shard (testing only; 1.0 = the named workload)")
+                    help="scale every scaffold length of the workload (testing only; 1.0 = the named workload)")
+    ap.add_argument("--workload", choices=("c5", "shard"), default="c5",
+                    help="c5: the whole C5 shape per GPU (the headline); shard: one 1/8 LPT shard of it per GPU (what rounds 1-3 "
+                         "reported; profiling runs)")
     ap.add_argument("--cpu-windows", type=int, default=150, help="windows in the CPU-baseline sample, ~0.1 s each (0 = skip)")
-    ap.add_argument("--no-upload", action="store_true", help="skip the upload-inclusive measurements")
+    ap.add_argument("--no-upload", action="store_true", help="skip the `inclusive` block (H2D-inclusive jobs from host memory)")
     ap.add_argument("--repeats", type=float, default=0.0,
                     help="simple repeats per kb in the synthetic shard (profiling runs of the `realistic` shape: 0.35; the headline metric is 0)")
     ap.add_argument("--no-extra", action="store_true", help="skip the cold / strong / realistic blocks (profiling runs)")
@@ -349,7 +387,8 @@ def main(argv=None):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from frisk_amd import Engine, synth
-    lens = [max(1, int(x * opts.shard_scale)) for x in synth.c5_shard_lens(8, rank % 8)]
+    base_lens = c5_lens() if opts.workload == "c5" else synth.c5_shard_lens(8, rank % 8)
+    lens = [max(1, int(x * opts.shard_scale)) for x in base_lens]
     eng = Engine(KMIN, KMAX, device=local_rank)
     eng.synth(lens, seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0, repeats_per_kb=opts.repeats)
     n_cand = eng.scan_plan(W, INC)
@@ -393,25 +432,27 @@ def main(argv=None):
         rows_all, bases_all, cand_all = float(rows), float(total_bases), float(n_cand)
 
     shard_kw = dict(seed=0xC5 + rank, island_frac=0.02, n_frac=0.07, lower_frac=0.0, repeats_per_kb=opts.repeats)
-    cold = strong = None
+    cold = strong = shard = None
     realistic = []
     if not opts.no_extra:
         few = max(2, min(opts.steps, 10))
         cold_ms, cold_scan_ms, _ = cold_step(eng, (lens, shard_kw), step, fence)
         cold = {"cold_first_step_ms": cold_ms, "cold_first_scan_kernel_ms": cold_scan_ms,
-                "note": "first step on a batch that has just become resident: includes the sample (every 32nd chunk) of the adaptive counter "
-                        "width and its host synchronisation; the steps behind `value` reuse the sample's verdict"}
-        strong = strong_block(eng, dist, torch, rank, world, red_dev, fence, few)
-        if world == 1:
+                "note": "first step on a batch that has just become resident: includes the sample (one round of the launch's workgroups) of "
+                        "the adaptive counter width; the steps behind `value` reuse the sample's verdict"}
+        if world > 1:
+            strong = strong_block(eng, dist, torch, rank, world, red_dev, fence, few)
+        if world == 1 and opts.shard_scale == 1.0:
+            shard, slens = shard_block(eng, rank, lambda: step, fence, few)
             for label, kw in (("unmasked assembly with simple repeats", synth.REPEATS_UNMASKED),
                               ("soft-masked assembly with simple repeats", synth.REPEATS_SOFT)):
-                realistic.append(shape_block(eng, lens, dict(kw, seed=0xC5 + rank), step, fence, few, label))
-        eng.synth(lens, **shard_kw)         # the headline shard again (upload block, CPU baselines)
+                realistic.append(shape_block(eng, slens, dict(kw, seed=0xC5 + rank), step, fence, few, label))
+        eng.synth(lens, **shard_kw)         # the headline batch again (inclusive block, CPU baselines)
         step()
         fence()
-    upload = None
+    inclusive = None
     if world == 1 and not opts.no_upload:
-        upload = upload_inclusive(eng, lens, step, fence, opts.steps, rows)
+        inclusive = inclusive_block(eng, lens, step, fence, max(2, min(opts.steps, 6)), rows, total_bases)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / opts.steps
@@ -424,27 +465,28 @@ def main(argv=None):
         traffic, binding, pmc_src = None, None, None
         # HBM traffic and issue counters: rocprofv3 --pmc passes of THIS workload, collected offline (separate runs, never
         # combined with tracing) and committed; valid only for the same shard and the same kernel
-        tpath = os.path.join(ROOT, "profiles", "r3_pmc_bench.json")
+        tpath = os.path.join(ROOT, "profiles", "r4_pmc_bench.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             same_work = tj.get("workload_bases_per_gpu") == total_bases and tj.get("candidate_windows_per_gpu") == n_cand
             # ... and only for the SOURCES the profile was taken from: the file carries their hash and the profiled kernel's name
             if same_work and tj.get("csrc_sha256") == csrc_hash():
-                pmc_src = ("profiles/r3_pmc_bench.json (offline rocprofv3 --pmc passes of this workload and of these sources - "
+                pmc_src = ("profiles/r4_pmc_bench.json (offline rocprofv3 --pmc passes of this workload and of these sources - "
                            "csrc_sha256 matches; kernel %s; not measured in this run)" % tj.get("kernel"))
                 traffic = tj.get("hbm_bytes_per_launch")
                 binding = tj.get("binding")
             else:
-                pmc_src = ("profiles/r3_pmc_bench.json was taken from other sources or another workload (csrc_sha256 / sizes "
+                pmc_src = ("profiles/r4_pmc_bench.json was taken from other sources or another workload (csrc_sha256 / sizes "
                            "differ): traffic and binding not quoted")
         out = {
             "metric": "windows/sec (k=1..8, w=5kb, s=1kb)", "value": rows_all / (elapsed / opts.steps),
             "unit": "windows/s", "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u4 counts + f64 scores", "data": "synthetic",
-            "config": {"workload": "C5 shape (GRCh38-like synthetic, 24 chromosome-scale + 400 small scaffolds, 7% N), "
-                                   "one 1/8 LPT shard per GPU (N=8 is the full 3.1 Gb job), k=1..8 w=5000 i=1000; "
-                                   "step = genome profile + all-reduce + window scan, inputs packed and resident in HBM",
+            "config": {"workload": ("C5: the whole GRCh38-like synthetic assembly (24 chromosome-scale + 400 small scaffolds, 3.29 Gb, 7% N) "
+                                    "on every GPU" if opts.workload == "c5" else
+                                    "one 1/8 LPT shard of the C5 shape (GRCh38-like synthetic, 7% N) per GPU") +
+                                   ", k=1..8 w=5000 i=1000; step = genome profile + all-reduce + window scan, inputs packed and resident in HBM",
                        "bases_per_gpu": total_bases, "candidate_windows_per_gpu": n_cand, "rows_per_gpu_rank0": rows,
                        "shard_scale": opts.shard_scale, **({"simple_repeats_per_kb": opts.repeats} if opts.repeats else {})},
             "gbases_per_s": bases_all / (elapsed / opts.steps) / 1e9,
@@ -459,8 +501,8 @@ def main(argv=None):
             "scan_row_segments": row_segments,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
-                         "traffic_note": "bytes at the L2's fabric side per scan (2 x FETCH_SIZE + WRITE_SIZE; Infinity Cache hits included).  Since "
-                                         "round 3 almost all of it is the per-workgroup ring that carries genome-side values from window to window "
+                         "traffic_note": "bytes at the L2's fabric side per scan (2 x FETCH_SIZE + WRITE_SIZE; Infinity Cache hits included).  Most "
+                                         "of it is the per-workgroup ring that carries genome-side values from window to window "
                                          "(61 MB in all: beyond L2, inside the 256 MB Infinity Cache) - traded for a 3.5 x cut of the L2 -> L1 line "
                                          "traffic that bound the kernel (`l2_gather`)",
                          "kernel": "scan8_kernel: the two bulk launches of a scan (about 15/16 of the rows, and the rest - whole rounds of the launch's workgroups - on a second stream while the first rows go to the host) + its hand-over launches and finish_rows_kernel: scan_kernel_ms spans them",
@@ -468,8 +510,8 @@ def main(argv=None):
                          "bulk_launches_per_scan": row_segments,
                          "duration_ms": scan_avg,
                          "duration_note": "achieved = algorithmic bytes of ONE SCAN / HIP-event time over all of its launches; "
-                                          "rocprofv3 --stats lists the bulk kernel with two launches per scan (about 7.6 ms + "
-                                          "0.6 ms, one after the other): its 'average' there is their mean, the scan is their sum",
+                                          "rocprofv3 --stats lists the bulk kernel with two launches per scan (the bulk of the rows, then "
+                                          "a tail of whole rounds of workgroups on a second stream): its 'average' there is their mean, the scan is their sum",
                          "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
                                  "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding` and `l2_gather`"},
             # what did bind until round 3: every scored position reads 8 bytes of the 512 KB genome table at a random
@@ -486,10 +528,11 @@ def main(argv=None):
                         "up to the lanes that hold them) and read / park the rest as coalesced doubles" % chunk})(W - KMAX + 1, 16),
             "binding": binding,
             **({"rehearsal_on_one_gpu": True} if rehearsal else {}),
+            "inclusive": inclusive,
             "cold": cold,
+            "shard": shard,
             "strong": strong,
             "realistic": realistic,
-            "upload": upload,
         }
         if opts.cpu_windows > 0:
             cb, worst, np_line, c_line = cpu_baseline(eng, lens[0], opts.cpu_windows)

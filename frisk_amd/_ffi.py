@@ -26,6 +26,10 @@ SYMBOLS = [
     ("frisk_seq_load", C.c_int, [_P, C.POINTER(C.c_char_p), _I64P, C.c_int32]),
     ("frisk_seq_stage", C.c_int, [_P, C.POINTER(C.c_void_p), _I64P, C.c_int32]),
     ("frisk_seq_stage_packed", C.c_int, [_P, _P, _P, _P, _I64P, C.c_int32]),
+    ("frisk_seq_stage_2bit", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, _I64P, C.c_int32, C.c_int64]),
+    ("frisk_pack_2bit", C.c_int, [C.POINTER(C.c_void_p), _I64P, C.c_int32, _P, C.POINTER(C.c_void_p), _I64P, C.POINTER(C.c_void_p), _I64P]),
+    ("frisk_padded_len_of", C.c_int64, [_I64P, C.c_int32]),
+    ("frisk_seq_export_2bit", C.c_int, [_P, _P, C.POINTER(C.c_void_p), _I64P, C.POINTER(C.c_void_p), _I64P]),
     ("frisk_seq_commit", C.c_int, [_P]),
     ("frisk_seq_export_packed", C.c_int, [_P, _P, _P, _P]),
     ("frisk_seq_set_names", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int32]),
@@ -62,6 +66,9 @@ SYMBOLS = [
     ("frisk_last_scan_stat", C.c_int64, [_P, C.c_int]),
     ("frisk_format_rows", C.c_void_p, [C.c_int64, C.POINTER(C.c_char_p), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64P]),
     ("frisk_free", None, [_P]),
+    ("frisk_hmm_fit", C.c_int, [_P, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P,
+                                C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    ("frisk_hmm_viterbi", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     ("frisk_host_alloc", C.c_void_p, [_P, C.c_int64]),
     ("frisk_host_free", None, [_P, _P]),
     ("frisk_last_kernel_ms", C.c_double, [_P, C.c_int]),

@@ -25,6 +25,8 @@
 #include "table_text.h"
 #include "fasta_index.h"
 #include "fasta_reader.h"
+#include "seq_pack2.h"
+#include "hmm_host.h"
 
 #ifndef FRISK_K7_WPS
 #define FRISK_K7_WPS 4              // waves per SIMD (= 256-thread workgroups per CU) of the K = 6, 7 narrow-counter kernels
@@ -94,7 +96,22 @@ struct frisk_ctx {
         int64_t cand_begin = 0, cand_end = 0;       // the rank's range of the job's candidate numbering
         std::vector<std::string> g_name;            // all records of the FASTA
         std::vector<int64_t> g_len;
-        void release() { d_ascii.release(); d_codes.release(); d_inv.release(); d_low.release(); }
+        // A STREAMED batch (frisk_seq_stage_2bit): the codes arrive in pieces on the copy stream; piece i - bitmap words
+        // [piece_end[i-1], piece_end[i]) and their code words - is complete when piece_ev[i] has passed.  `streaming`: the compute
+        // stream has not waited for them yet (frisk_profile_add follows the pieces one by one; anything else waits for the last).
+        std::vector<int64_t> piece_end;
+        std::vector<hipEvent_t> piece_ev;
+        bool streaming = false;
+        DevBuf<int64_t> d_runs;                     // the run lists of the two masks and of the PADs, as uploaded
+        int64_t* h_pads = nullptr;                  // page-locked: the PAD runs on their way to the device
+        size_t h_pads_cap = 0;
+        void release() {
+            d_ascii.release(); d_codes.release(); d_inv.release(); d_low.release(); d_runs.release();
+            if (h_pads) (void)hipHostFree(h_pads);
+            h_pads = nullptr; h_pads_cap = 0;
+            for (hipEvent_t e : piece_ev) (void)hipEventDestroy(e);
+            piece_ev.clear();
+        }
     };
     Batch bat[2];
     int cur = 0;
@@ -186,6 +203,7 @@ int layout_batch(frisk_ctx* c, frisk_ctx::Batch& B, const int64_t* lens, int32_t
     B.width_hint = 0;
     B.tiled = false;
     B.tiles.clear(); B.g_name.clear(); B.g_len.clear();
+    B.streaming = false;        // (piece_end is kept: frisk_seq_stage_2bit looks at the slot's previous upload)
     return FRISK_OK;
 }
 int layout_batch(frisk_ctx* c, const int64_t* lens, int32_t n_seq) { return layout_batch(c, c->b(), lens, n_seq); }
@@ -283,6 +301,15 @@ int enqueue_ascii_upload(frisk_ctx* c, frisk_ctx::Batch& B, const uint8_t* const
             const int rc = h2d(c, B.d_ascii.p + B.seq_off[size_t(s)], seqs[s], size_t(lens[s]), st);
             if (rc) return rc;
         }
+    return FRISK_OK;
+}
+
+// A streamed batch (frisk_seq_stage_2bit) whose pieces the compute stream has not followed: wait, on the device, for the last
+int settle_stream(frisk_ctx* c) {
+    frisk_ctx::Batch& B = c->b();
+    if (!B.streaming) return FRISK_OK;
+    if (!B.piece_end.empty()) HIPC(c, hipStreamWaitEvent(c->stream, B.piece_ev[B.piece_end.size() - 1], 0));
+    B.streaming = false;
     return FRISK_OK;
 }
 
@@ -878,6 +905,125 @@ int frisk_seq_stage_packed(frisk_ctx* c, const uint32_t* codes, const uint32_t* 
     return FRISK_OK;
 }
 
+// ---- the 0.25 B/base upload form: 2-bit codes densely, the two masks as run lists, the codes in pieces --------------------
+int64_t frisk_padded_len_of(const int64_t* lens, int32_t n_seq) {
+    if (n_seq < 0 || (n_seq > 0 && !lens)) return -1;
+    for (int32_t s = 0; s < n_seq; ++s) if (lens[s] < 0) return -1;
+    return frisk_pack2::padded_len(lens, n_seq);
+}
+
+int frisk_pack_2bit(const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq, uint32_t* codes, int64_t** inv_runs,
+                    int64_t* n_inv, int64_t** low_runs, int64_t* n_low) {
+    if (n_seq < 0 || (n_seq > 0 && (!seqs || !lens)) || !codes || !inv_runs || !n_inv || !low_runs || !n_low) return FRISK_E_ARG;
+    for (int32_t s = 0; s < n_seq; ++s) if (lens[s] < 0 || (lens[s] > 0 && !seqs[s])) return FRISK_E_ARG;
+    frisk_pack2::Runs R;
+    const unsigned hw = std::thread::hardware_concurrency();
+    frisk_pack2::pack_batch(seqs, lens, n_seq, codes, R, int(std::min(32u, hw ? hw : 1u)));
+    auto give = [](const std::vector<int64_t>& v, int64_t** out, int64_t* n) -> bool {
+        *n = int64_t(v.size() / 2);
+        *out = static_cast<int64_t*>(std::malloc(std::max<size_t>(v.size(), 2) * sizeof(int64_t)));
+        if (!*out) return false;
+        if (!v.empty()) std::memcpy(*out, v.data(), v.size() * sizeof(int64_t));
+        return true;
+    };
+    if (!give(R.inv, inv_runs, n_inv)) return FRISK_E_HIP;
+    if (!give(R.low, low_runs, n_low)) { std::free(*inv_runs); *inv_runs = nullptr; return FRISK_E_HIP; }
+    return FRISK_OK;
+}
+
+// one mask of a streamed batch: zero the bitmap, then the caller's run list (or the caller's dense bitmap), then the PADs
+static int enqueue_mask(frisk_ctx* c, frisk_ctx::Batch& B, uint32_t* d_bits, const int64_t* runs, int64_t n_runs, int64_t* d_runs,
+                        const int64_t* d_pads, int64_t n_pads, hipStream_t st) {
+    const size_t w32 = size_t(B.padded_len / 32);
+    if (n_runs < 0) {               // dense: P / 32 words in the library's layout (real bases only; PADs are added here)
+        int rc = h2d(c, d_bits, runs, w32 * 4, st);
+        if (rc) return rc;
+    } else {
+        HIPC(c, hipMemsetAsync(d_bits, 0, w32 * 4, st));
+        if (n_runs > 0) {
+            int rc = h2d(c, d_runs, runs, size_t(n_runs) * 16, st);
+            if (rc) return rc;
+            expand_runs_kernel<<<grid_for(n_runs, 4, c->num_cu * 16), 256, 0, st>>>(d_runs, n_runs, d_bits);
+            HIPC(c, hipGetLastError());
+        }
+    }
+    expand_runs_kernel<<<grid_for(n_pads, 4, c->num_cu * 16), 256, 0, st>>>(d_pads, n_pads, d_bits);
+    HIPC(c, hipGetLastError());
+    return FRISK_OK;
+}
+
+int frisk_seq_stage_2bit(frisk_ctx* c, const uint32_t* codes, const int64_t* inv_runs, int64_t n_inv, const int64_t* low_runs,
+                         int64_t n_low, const int64_t* lens, int32_t n_seq, int64_t piece_bases) {
+    if (!c) return FRISK_E_ARG;
+    if (!codes || (n_seq > 0 && !lens) || (n_inv != 0 && !inv_runs) || (n_low != 0 && !low_runs))
+        return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: null array");
+    if (piece_bases < 0) return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: piece_bases < 0");
+    HIPC(c, hipSetDevice(c->device));
+    frisk_ctx::Batch& B = c->bat[c->cur ^ 1];
+    c->staged = false;
+    if (c->slot_ev_set) HIPC(c, hipStreamWaitEvent(c->copy_stream, c->slot_free_ev, 0));      // (as frisk_seq_stage)
+    int rc = layout_batch(c, B, lens, n_seq);
+    if (rc) return rc;
+    const int64_t P = B.padded_len;
+    for (const auto& L : {std::make_pair(inv_runs, n_inv), std::make_pair(low_runs, n_low)})
+        for (int64_t r = 0; r < L.second; ++r)
+            if (L.first[2 * r] < 0 || L.first[2 * r] > L.first[2 * r + 1] || L.first[2 * r + 1] > P)
+                return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: a run outside the batch");
+    rc = alloc_packed(c, B, c->copy_stream);
+    if (rc) return rc;
+    // PAD runs: the position behind every scaffold, and the batch's tail (inv AND low, frisk_device.h); adjacent ones merged
+    // (the page-locked buffer they travel from may still feed the copy of this slot's previous upload: wait for that one)
+    if (!B.piece_end.empty() && !B.piece_ev.empty()) HIPC(c, hipEventSynchronize(B.piece_ev[std::min(B.piece_end.size(), B.piece_ev.size()) - 1]));
+    std::vector<int64_t> pads;
+    for (int32_t s = 0; s < n_seq; ++s) frisk_pack2::push_run(pads, B.seq_off[size_t(s)] + lens[s], B.seq_off[size_t(s)] + lens[s] + 1);
+    {
+        const int64_t tail = n_seq > 0 ? B.seq_off[size_t(n_seq) - 1] + lens[n_seq - 1] + 1 : 0;
+        if (tail < P) frisk_pack2::push_run(pads, tail, P);
+    }
+    const int64_t n_pads = int64_t(pads.size() / 2);
+    const size_t need = 2 * size_t(std::max<int64_t>(n_inv, 0) + std::max<int64_t>(n_low, 0) + n_pads) + 8;
+    HIPC(c, B.d_runs.reserve(need));
+    int64_t* d_pads = B.d_runs.p;
+    int64_t* d_inv_runs = d_pads + 2 * n_pads;
+    int64_t* d_low_runs = d_inv_runs + 2 * std::max<int64_t>(n_inv, 0);
+    if (B.h_pads_cap < pads.size()) {
+        if (B.h_pads) HIPC(c, hipHostFree(B.h_pads));
+        B.h_pads = nullptr; B.h_pads_cap = 0;
+        HIPC(c, hipHostMalloc(reinterpret_cast<void**>(&B.h_pads), (pads.size() + pads.size() / 4 + 16) * sizeof(int64_t), hipHostMallocDefault));
+        B.h_pads_cap = pads.size() + pads.size() / 4 + 16;
+    }
+    std::memcpy(B.h_pads, pads.data(), pads.size() * sizeof(int64_t));
+    HIPC(c, hipMemcpyAsync(d_pads, B.h_pads, pads.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->copy_stream));
+    rc = enqueue_mask(c, B, B.d_inv.p, inv_runs, n_inv, d_inv_runs, d_pads, n_pads, c->copy_stream);
+    if (rc) return rc;
+    rc = enqueue_mask(c, B, B.d_low.p, low_runs, n_low, d_low_runs, d_pads, n_pads, c->copy_stream);
+    if (rc) return rc;
+    // the codes, piece by piece: an event behind each, so that phase A can follow the copies (frisk_profile_add)
+    const int64_t w32 = P / 32;
+    int64_t piece_words = (piece_bases ? piece_bases : (int64_t(1) << 26)) / 32;          // default: 64 Mbases = 16 MB of codes
+    if (piece_words < 1) piece_words = 1;
+    const int64_t n_pieces = std::max<int64_t>(1, (w32 + piece_words - 1) / piece_words);
+    if (n_pieces > 4096) piece_words = (w32 + 4095) / 4096;
+    B.piece_end.clear();
+    for (int64_t a = 0; a < w32; a += piece_words) {
+        const int64_t b = std::min(w32, a + piece_words);
+        rc = h2d(c, B.d_codes.p + 2 * a, codes + 2 * a, size_t(b - a) * 8, c->copy_stream);
+        if (rc) return rc;
+        const size_t i = B.piece_end.size();
+        if (B.piece_ev.size() <= i) {
+            hipEvent_t ev = nullptr;
+            HIPC(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            B.piece_ev.push_back(ev);
+        }
+        HIPC(c, hipEventRecord(B.piece_ev[i], c->copy_stream));
+        B.piece_end.push_back(b);
+    }
+    HIPC(c, hipEventRecord(c->staged_ev, c->copy_stream));
+    B.streaming = true;
+    c->staged = true;
+    return FRISK_OK;
+}
+
 int frisk_seq_commit(frisk_ctx* c) {
     if (!c) return FRISK_E_ARG;
     if (!c->staged) return fail(c, FRISK_E_STATE, "frisk_seq_commit: no staged batch");
@@ -885,7 +1031,8 @@ int frisk_seq_commit(frisk_ctx* c) {
     // the slot that stops being resident here is the one the next stage fills: that upload waits for what is queued so far
     HIPC(c, hipEventRecord(c->slot_free_ev, c->stream));
     c->slot_ev_set = true;
-    HIPC(c, hipStreamWaitEvent(c->stream, c->staged_ev, 0));   // the compute stream waits on the device; the host does not
+    // the compute stream waits on the device; the host does not.  A streamed batch is waited for piece by piece, by its first user
+    if (!c->bat[c->cur ^ 1].streaming) HIPC(c, hipStreamWaitEvent(c->stream, c->staged_ev, 0));
     c->cur ^= 1;
     c->b().have_seq = true;
     c->staged = false;
@@ -893,10 +1040,40 @@ int frisk_seq_commit(frisk_ctx* c) {
     return FRISK_OK;
 }
 
+int frisk_seq_export_2bit(frisk_ctx* c, uint32_t* codes, int64_t** inv_runs, int64_t* n_inv, int64_t** low_runs, int64_t* n_low) {
+    if (!c || !codes || !inv_runs || !n_inv || !low_runs || !n_low) return FRISK_E_ARG;
+    if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
+    HIPC(c, hipSetDevice(c->device));
+    int rc = settle_stream(c);
+    if (rc) return rc;
+    const frisk_ctx::Batch& B = c->b();
+    const size_t w32 = size_t(B.padded_len / 32);
+    std::vector<uint32_t> inv(w32), low(w32);
+    HIPC(c, hipMemcpyAsync(codes, B.d_codes.p, 2 * w32 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(inv.data(), B.d_inv.p, w32 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(low.data(), B.d_low.p, w32 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    std::vector<int64_t> ri, rl;
+    std::thread t([&] { frisk_pack2::bitmap_runs(inv.data(), B.seq_len.data(), B.n_seq, ri); });
+    frisk_pack2::bitmap_runs(low.data(), B.seq_len.data(), B.n_seq, rl);
+    t.join();
+    auto give = [](const std::vector<int64_t>& v, int64_t** out, int64_t* n) -> bool {
+        *n = int64_t(v.size() / 2);
+        *out = static_cast<int64_t*>(std::malloc(std::max<size_t>(v.size(), 2) * sizeof(int64_t)));
+        if (!*out) return false;
+        if (!v.empty()) std::memcpy(*out, v.data(), v.size() * sizeof(int64_t));
+        return true;
+    };
+    if (!give(ri, inv_runs, n_inv)) return fail(c, FRISK_E_HIP, "out of host memory");
+    if (!give(rl, low_runs, n_low)) { std::free(*inv_runs); *inv_runs = nullptr; return fail(c, FRISK_E_HIP, "out of host memory"); }
+    return FRISK_OK;
+}
+
 int frisk_seq_export_packed(frisk_ctx* c, uint32_t* codes, uint32_t* inv, uint32_t* low) {
     if (!c || !codes || !inv || !low) return FRISK_E_ARG;
     if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
     HIPC(c, hipSetDevice(c->device));
+    if (int rs = settle_stream(c)) return rs;
     const size_t w32 = size_t(c->b().padded_len / 32);
     HIPC(c, hipMemcpyAsync(codes, c->b().d_codes.p, 2 * w32 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipMemcpyAsync(inv, c->b().d_inv.p, w32 * 4, hipMemcpyDeviceToHost, c->stream));
@@ -947,6 +1124,7 @@ int frisk_seq_read(frisk_ctx* c, int32_t s, int64_t offset, int64_t n, uint8_t* 
     if (offset < 0 || n < 0 || offset + n > c->b().seq_len[size_t(s)]) return fail(c, FRISK_E_ARG, "range outside the scaffold");
     if (n == 0) return FRISK_OK;
     HIPC(c, hipSetDevice(c->device));
+    if (int rs = settle_stream(c)) return rs;
     DevBuf<uint8_t> tmp;
     HIPC(c, tmp.reserve(size_t(n)));
     unpack_kernel<<<grid_for(n, 256, c->num_cu * 8), 256, 0, c->stream>>>(c->b().d_codes.p, c->b().d_inv.p, c->b().d_low.p,
@@ -968,7 +1146,7 @@ int frisk_profile_reset(frisk_ctx* c) {
     return FRISK_OK;
 }
 
-static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1);
+static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1, bool first = true, bool last = true);
 
 int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
     if (!c) return FRISK_E_ARG;
@@ -986,24 +1164,44 @@ int frisk_profile_add(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
         }
         return FRISK_OK;
     }
+    frisk_ctx::Batch& SB = c->b();
+    if (SB.streaming && p0 < 0 && p1 < 0 && !SB.piece_end.empty()) {
+        // a streamed batch counted as a whole: phase A follows the copies piece by piece - the kernel of piece i runs while piece
+        // i + 1 crosses PCIe, only the last piece's kernel is left when the upload ends.  A lane that counts the positions of
+        // bitmap word q reads word q + 1 of the masks and code word 2 q + 2, so piece i's kernel stops one word short of its end.
+        HIPC(c, hipSetDevice(c->device));
+        const size_t np = SB.piece_end.size();
+        int64_t done = 0;
+        for (size_t i = 0; i < np; ++i) {
+            HIPC(c, hipStreamWaitEvent(c->stream, SB.piece_ev[i], 0));
+            const int64_t upto = i + 1 == np ? SB.padded_len : (SB.piece_end[i] - 1) * 32;
+            if (upto > done || i + 1 == np || i == 0) {
+                int rc = profile_add_range(c, mask_host, done, std::max(done, upto), i == 0, i + 1 == np);
+                if (rc) return rc;
+                done = std::max(done, upto);
+            }
+        }
+        SB.streaming = false;
+        return FRISK_OK;
+    }
+    if (int rs = settle_stream(c)) return rs;
     return profile_add_range(c, mask_host, p0, p1);
 }
 
-static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1) {
+static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1, bool first, bool last) {
     if (p0 < 0 && p1 < 0) { p0 = 0; p1 = c->b().padded_len; }
     if (p0 < 0 || p1 > c->b().padded_len || p0 > p1) return fail(c, FRISK_E_ARG, "position range outside the batch");
     HIPC(c, hipSetDevice(c->device));
     c->profile_final = false;
     if (c->kmax > 8) {          // 4^K counters do not fit a CU: one global atomic per position (profile_kernels.h)
         const int64_t nw = p1 > p0 ? ((p1 + 31) >> 5) - (p0 >> 5) : 0;
-        HIPC(c, hipEventRecord(c->evp0, c->stream));
+        if (first) HIPC(c, hipEventRecord(c->evp0, c->stream));
         if (nw > 0)
             profile_add_big_kernel<<<grid_for(nw, 256, c->num_cu * 8), 256, 0, c->stream>>>(
                 c->b().d_codes.p, c->b().d_inv.p, c->b().d_low.p, p0, p1, c->kmin, c->kmax, mask_host ? 1 : 0, int(c->nprof),
                 reinterpret_cast<unsigned long long*>(c->d_raw.p));
         HIPC(c, hipGetLastError());
-        HIPC(c, hipEventRecord(c->evp1, c->stream));
-        c->ms_pending[1] = true;
+        if (last) { HIPC(c, hipEventRecord(c->evp1, c->stream)); c->ms_pending[1] = true; }
         return FRISK_OK;
     }
     // order-K table privatised in LDS (u32): split in two halves at K = 8 (256 KiB does not fit a CU)
@@ -1017,7 +1215,7 @@ static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1
     int64_t nchunks = std::min<int64_t>(std::max<int64_t>(1, span / 65536), int64_t(c->num_cu) * FRISK_PROF_WG_PER_CU / halves);
     const int64_t chunk_len = (nwords + nchunks - 1) / std::max<int64_t>(nchunks, 1);   // in words
     nchunks = chunk_len > 0 ? (nwords + chunk_len - 1) / chunk_len : 0;
-    HIPC(c, hipEventRecord(c->evp0, c->stream));
+    if (first) HIPC(c, hipEventRecord(c->evp0, c->stream));
     if (span > 0) {
         auto raw = reinterpret_cast<unsigned long long*>(c->d_raw.p);
         HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(profile_add_kernel),
@@ -1027,8 +1225,10 @@ static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1
             chunk_len, raw);
     }
     HIPC(c, hipGetLastError());
-    HIPC(c, hipEventRecord(c->evp1, c->stream));
-    c->ms_pending[1] = true;        // asynchronous: the elapsed time is read when frisk_last_kernel_ms(1) asks for it
+    if (last) {
+        HIPC(c, hipEventRecord(c->evp1, c->stream));
+        c->ms_pending[1] = true;    // asynchronous: the elapsed time is read when frisk_last_kernel_ms(1) asks for it
+    }
     return FRISK_OK;
 }
 
@@ -1199,6 +1399,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
     c->ms[0] = 0.0;
     if (n == 0) return FRISK_OK;
     HIPC(c, hipSetDevice(c->device));
+    if (int rs = settle_stream(c)) return rs;
     const bool debug = dbg_counts || dbg_meta;
     const size_t N = size_t(n);
     HIPC(c, c->o_seq.reserve(N)); HIPC(c, c->o_start.reserve(N)); HIPC(c, c->o_stop.reserve(N));
@@ -1606,6 +1807,32 @@ char* frisk_format_rows(int64_t n, const char* const* names, const int32_t* seq_
     return frisk_text::format_all(c, out_len);
 }
 void frisk_free(void* p) { std::free(p); }
+
+// ---- host-native 2-state Gaussian HMM (hmm_host.h): the model frisk_amd/hmm.py documents, for millions of windows ----------
+int frisk_hmm_fit(const double* x, int64_t n, int32_t n_iter, double tol, double min_covar, double covars_prior, double* means,
+                  double* covars, double* startprob, double* transmat, double* loglik, int32_t* iters) {
+    if (!x || n < 1 || n_iter < 0 || !means || !covars || !startprob || !transmat) return FRISK_E_ARG;
+    for (int64_t t = 0; t < n; ++t) if (!std::isfinite(x[t])) return FRISK_E_ARG;
+    const frisk_hmm::Fit F = frisk_hmm::fit(x, n, n_iter, tol, min_covar, covars_prior);
+    for (int i = 0; i < 2; ++i) { means[i] = F.m.means[i]; covars[i] = F.m.covars[i]; startprob[i] = F.m.startprob[i]; }
+    for (int i = 0; i < 4; ++i) transmat[i] = F.m.transmat[i];
+    if (loglik) *loglik = F.loglik;
+    if (iters) *iters = F.iters;
+    return FRISK_OK;
+}
+
+int frisk_hmm_viterbi(const double* x, const int64_t* seg_off, int32_t n_seg, const double* means, const double* covars,
+                      const double* startprob, const double* transmat, int8_t* states) {
+    if (n_seg < 0 || !seg_off || !means || !covars || !startprob || !transmat) return FRISK_E_ARG;
+    for (int32_t s = 0; s < n_seg; ++s) if (seg_off[s + 1] < seg_off[s]) return FRISK_E_ARG;
+    if (n_seg == 0 || seg_off[n_seg] == seg_off[0]) return FRISK_OK;
+    if (!x || !states) return FRISK_E_ARG;
+    frisk_hmm::Model m;
+    for (int i = 0; i < 2; ++i) { m.means[i] = means[i]; m.covars[i] = covars[i]; m.startprob[i] = startprob[i]; }
+    for (int i = 0; i < 4; ++i) m.transmat[i] = transmat[i];
+    frisk_hmm::viterbi_segments(x, seg_off, n_seg, m, states);
+    return FRISK_OK;
+}
 
 int64_t frisk_last_scan_stat(const frisk_ctx* c, int which) { return (c && which >= 0 && which < 5) ? c->scan_stat[which] : -1; }
 

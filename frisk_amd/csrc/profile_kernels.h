@@ -60,6 +60,30 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict_
     }
 }
 
+// Run lists -> bitmap (the 0.25 B/base upload form, seq_pack2.h): `runs` holds n_runs pairs [begin, end) of padded positions,
+// disjoint within one list; every position of a run gets its bit set (position p = bit 31 - (p & 31) of word p >> 5).  One
+// wavefront per run: whole words inside a run are plain stores (a word covered entirely by one run belongs to no other run
+// of the list), the ragged first / last word an atomic OR (another list - the PADs - may share it).  The bitmap was zeroed
+// on the same stream.  HBM-bound at 1 bit per covered position; a list of millions of short runs costs a wave each.
+__global__ __launch_bounds__(256) void expand_runs_kernel(const int64_t* __restrict__ runs, int64_t n_runs,
+                                                           uint32_t* __restrict__ bits) {
+    const int lane = int(threadIdx.x & 63u);
+    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_runs; r += nwaves) {
+        const int64_t b = runs[2 * r], e = runs[2 * r + 1];
+        if (e <= b) continue;
+        const int64_t w0 = b >> 5, w1 = (e - 1) >> 5;
+        for (int64_t w = w0 + lane; w <= w1; w += 64) {
+            const int64_t lo = w << 5;
+            const int from = b > lo ? int(b - lo) : 0, to = e < lo + 32 ? int(e - lo) : 32;      // bits [from, to) of the word
+            const uint32_t m = uint32_t((0xFFFFFFFFull >> from) & ~(0xFFFFFFFFull >> to));
+            if (m == 0xFFFFFFFFu) bits[w] = m;
+            else atomicOr(bits + w, m);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Phase A counting.  Every padded position p contributes exactly ONE histogram update: to the table
 // of order r = min(run, K) at the code of its longest valid word, where run = number of consecutive

@@ -1,0 +1,150 @@
+// seq_pack2.h - host side of the 0.25 B/base upload form ("2-bit codes; N / lowercase as sparse interval lists").
+//
+// The resident layout of frisk_device.h needs three bit arrays per padded position: codes (2 bits), inv, low (1 bit each).
+// Over PCIe only the codes travel densely; the two masks travel as lists of half-open runs [begin, end) of padded positions
+// (N runs and soft-masked runs are few and long in assemblies) and are expanded to the bitmaps on the device
+// (expand_runs_kernel, profile_kernels.h).  PAD positions are known from the scaffold lengths and never travel.
+// Classification of a byte = classify_byte of profile_kernels.h (the device packer): ACGT / acgt -> code, everything else
+// invalid; lowercase acgt -> soft-masked (case-sensitive tallies of the reference: countN L106-118, calcGC L120-137).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace frisk_pack2 {
+
+// per byte: bits 0-1 code, bit 2 inv, bit 3 low
+struct Lut {
+    uint8_t t[256];
+    Lut() {
+        for (int c = 0; c < 256; ++c) t[c] = 4;                 // not one of ACGTacgt
+        const char* up = "ATGC";                                // A=0, T=1, G=2, C=3 (reference L70)
+        for (int d = 0; d < 4; ++d) {
+            t[uint8_t(up[d])] = uint8_t(d);
+            t[uint8_t(up[d] | 0x20)] = uint8_t(d | 8);          // lowercase: counted as a k-mer letter, soft-masked
+        }
+    }
+};
+inline const Lut& lut() { static const Lut L; return L; }
+
+inline int64_t padded_len(const int64_t* lens, int32_t n_seq) {
+    int64_t pos = 0;
+    for (int32_t s = 0; s < n_seq; ++s) pos += lens[s] + 1;
+    int64_t p = (pos + 31) / 32 * 32;
+    return p ? p : 32;
+}
+
+struct Runs {
+    std::vector<int64_t> inv, low;          // pairs begin, end (padded positions), ascending, disjoint, non-adjacent
+};
+
+// append [b, e) to a run list, merging with a run that ends at b
+inline void push_run(std::vector<int64_t>& v, int64_t b, int64_t e) {
+    if (!v.empty() && v.back() == b) v.back() = e;
+    else { v.push_back(b); v.push_back(e); }
+}
+
+// positions [p0, p1) of one scaffold piece: `src` = its bytes, codes written to the words of `codes` (2 bits per position,
+// big-endian in the word; the caller zeroed them), runs appended.  p0 is a multiple of 16 unless the piece starts a
+// scaffold - words shared by two pieces are written by ONE piece only because pieces are cut at multiples of 32.
+inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* codes, Runs& out) {
+    const uint8_t* T = lut().t;
+    int64_t inv_b = -1, low_b = -1;
+    int64_t p = p0;
+    const uint8_t* s = src;
+    while (p < p1) {
+        const int64_t wend = std::min<int64_t>(p1, (p | 15) + 1);       // positions of one code word
+        uint32_t word = 0;
+        for (; p < wend; ++p, ++s) {
+            const uint32_t v = T[*s];
+            word |= (v & 3u) << (30 - 2 * int(p & 15));
+            if (v & 4u) { if (inv_b < 0) inv_b = p; }
+            else if (inv_b >= 0) { push_run(out.inv, inv_b, p); inv_b = -1; }
+            if (v & 8u) { if (low_b < 0) low_b = p; }
+            else if (low_b >= 0) { push_run(out.low, low_b, p); low_b = -1; }
+        }
+        codes[(p - 1) >> 4] |= word;
+    }
+    if (inv_b >= 0) push_run(out.inv, inv_b, p1);
+    if (low_b >= 0) push_run(out.low, low_b, p1);
+}
+
+// The whole batch: scaffold s at padded positions [off[s], off[s] + lens[s]).  `codes`: 2 * P / 32 words, zeroed here.
+// Work is cut at multiples of 32 positions and dealt to `threads` workers; runs that cross a cut are merged afterwards.
+inline void pack_batch(const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq, uint32_t* codes, Runs& out, int threads) {
+    const int64_t P = padded_len(lens, n_seq);
+    std::vector<int64_t> off(size_t(n_seq) + 1, 0);
+    for (int32_t s = 0; s < n_seq; ++s) off[size_t(s) + 1] = off[size_t(s)] + lens[s] + 1;
+    const int64_t words32 = P / 32;
+    int T = std::max(1, threads);
+    if (P < (int64_t(1) << 22)) T = 1;
+    T = int(std::min<int64_t>(T, std::max<int64_t>(1, words32)));
+    std::vector<Runs> part{size_t(T)};
+    auto work = [&](int t) {
+        const int64_t a = words32 * t / T * 32, b = words32 * (t + 1) / T * 32;
+        std::memset(codes + a / 16, 0, size_t(b - a) / 16 * 4);
+        // scaffolds that meet [a, b)
+        int32_t s = int32_t(std::upper_bound(off.begin(), off.end(), a) - off.begin()) - 1;
+        if (s < 0) s = 0;
+        for (; s < n_seq && off[size_t(s)] < b; ++s) {
+            const int64_t q0 = std::max<int64_t>(a, off[size_t(s)]), q1 = std::min<int64_t>(b, off[size_t(s)] + lens[s]);
+            if (q1 > q0) pack_piece(seqs[s] + (q0 - off[size_t(s)]), q0, q1, codes, part[size_t(t)]);
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    size_t ni = 0, nl = 0;
+    for (const Runs& r : part) { ni += r.inv.size(); nl += r.low.size(); }
+    out.inv.clear(); out.low.clear();
+    out.inv.reserve(ni); out.low.reserve(nl);
+    for (const Runs& r : part) {
+        for (size_t k = 0; k + 1 < r.inv.size(); k += 2) push_run(out.inv, r.inv[k], r.inv[k + 1]);
+        for (size_t k = 0; k + 1 < r.low.size(); k += 2) push_run(out.low, r.low[k], r.low[k + 1]);
+    }
+}
+
+// The same from the parser's buffer (fasta_reader.h: records back to back, one PAD byte behind each): one source pointer.
+inline void pack_stage(const uint8_t* stage, const int64_t* lens, int32_t n_seq, uint32_t* codes, Runs& out, int threads) {
+    std::vector<const uint8_t*> ptr(size_t(std::max(n_seq, 1)));
+    int64_t pos = 0;
+    for (int32_t s = 0; s < n_seq; ++s) { ptr[size_t(s)] = stage + pos; pos += lens[s] + 1; }
+    pack_batch(ptr.data(), lens, n_seq, codes, out, threads);
+}
+
+// Runs of set bits of a bitmap over positions [0, P) (big-endian in the word), with the PAD positions - behind every
+// scaffold and behind the batch - taken out: the run lists of a batch that is resident as bitmaps (sequence cache).
+inline void bitmap_runs(const uint32_t* bits, const int64_t* lens, int32_t n_seq, std::vector<int64_t>& out) {
+    out.clear();
+    int64_t off = 0;
+    for (int32_t s = 0; s < n_seq; ++s) {
+        const int64_t a = off, b = off + lens[s];
+        int64_t p = a, run_b = -1;
+        while (p < b) {
+            const uint32_t w = bits[p >> 5];
+            const int r = int(p & 31);
+            const int64_t wend = std::min<int64_t>(b, (p | 31) + 1);
+            if (r == 0 && wend - p == 32 && (w == 0u || w == 0xFFFFFFFFu)) {           // whole words at once
+                if (w) { if (run_b < 0) run_b = p; }
+                else if (run_b >= 0) { push_run(out, run_b, p); run_b = -1; }
+                p = wend;
+                continue;
+            }
+            for (; p < wend; ++p) {
+                const bool set = (w >> (31 - int(p & 31))) & 1u;
+                if (set) { if (run_b < 0) run_b = p; }
+                else if (run_b >= 0) { push_run(out, run_b, p); run_b = -1; }
+            }
+        }
+        if (run_b >= 0) push_run(out, run_b, b);
+        off = b + 1;
+    }
+}
+
+}  // namespace frisk_pack2

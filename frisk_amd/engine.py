@@ -41,6 +41,30 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def pack_2bit_host(seqs):
+    """frisk_pack_2bit without a context (host-only entry point of the library): (codes, inv_runs, low_runs, lens) as ordinary
+    numpy arrays - the 0.25 B/base form `Engine.stage_2bit` uploads."""
+    lib = _ffi.lib()
+    arrs = [Engine._as_u8(s) for s in seqs]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+    lens = [int(a.size) for a in arrs]
+    clens = (C.c_int64 * max(n, 1))(*lens)
+    P = int(lib.frisk_padded_len_of(clens, n))
+    codes = np.empty(2 * P // 32, np.uint32)
+    pi, pl, ni, nl = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+    rc = lib.frisk_pack_2bit(ptrs, clens, n, _ptr(codes), C.byref(pi), C.byref(ni), C.byref(pl), C.byref(nl))
+    if rc != _ffi.OK:
+        raise _ffi.FriskHipError(rc, "frisk_pack_2bit failed")
+    runs = []
+    for ptr, cnt in ((pi, ni), (pl, nl)):
+        k = int(cnt.value)
+        a = np.frombuffer((C.c_int64 * (2 * k)).from_address(ptr.value), dtype=np.int64).copy() if k else np.empty(0, np.int64)
+        lib.frisk_free(ptr)
+        runs.append(a.reshape(k, 2))
+    return codes, runs[0], runs[1], lens
+
+
 class Engine:
     def __init__(self, kmin, kmax, device=0):
         self._lib = _ffi.lib()
@@ -146,6 +170,61 @@ class Engine:
         keep = [np.ascontiguousarray(a, dtype=np.uint32) for a in (codes, inv, low)]
         self._check(self._lib.frisk_seq_stage_packed(self._ctx, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), arr, len(lens)))
         self._staged = (keep, lens)
+
+    def pack_2bit(self, seqs, pinned=True):
+        """ASCII scaffolds -> the 0.25 B/base upload form, on the host (library threads): (codes, inv_runs, low_runs, lens).
+        codes: uint32[2 P / 32] (page-locked when pinned=True: its upload is then asynchronous); inv_runs / low_runs: int64[n, 2]
+        half-open runs of padded positions (letters other than ACGTacgt / lowercase acgt)."""
+        arrs = [self._as_u8(s) for s in seqs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        lens = [int(a.size) for a in arrs]
+        clens = (C.c_int64 * max(n, 1))(*lens)
+        P = int(self._lib.frisk_padded_len_of(clens, n))
+        codes = self.host_array("codes2", 2 * P // 32, np.uint32) if pinned else np.empty(2 * P // 32, np.uint32)
+        pi, pl, ni, nl = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+        self._check(self._lib.frisk_pack_2bit(ptrs, clens, n, _ptr(codes), C.byref(pi), C.byref(ni), C.byref(pl), C.byref(nl)))
+        return (codes,) + self._take_runs(pi, ni, pl, nl, pinned) + (lens,)
+
+    def _take_runs(self, pi, ni, pl, nl, pinned):
+        out = []
+        for tag, ptr, cnt in (("inv_runs", pi, ni), ("low_runs", pl, nl)):
+            k = int(cnt.value)
+            dst = self.host_array(tag, max(2 * k, 2), np.int64)[:2 * k] if pinned else np.empty(2 * k, np.int64)
+            if k:
+                dst[:] = np.frombuffer((C.c_int64 * (2 * k)).from_address(ptr.value), dtype=np.int64)
+            self._lib.frisk_free(ptr)
+            out.append(dst.reshape(k, 2))
+        return tuple(out)
+
+    def stage_2bit(self, codes, inv_runs, low_runs, lens, piece_bases=0):
+        """Start the streamed upload of the NEXT batch from the 0.25 B/base form (`pack_2bit` / `export_2bit`); `commit()` makes
+        it resident without waiting, and `profile_add()` on it follows the pieces of the upload.  inv_runs / low_runs: int64[n, 2]
+        run lists, or a uint32[P / 32] dense bitmap."""
+        lens = [int(x) for x in lens]
+        arr = (C.c_int64 * max(len(lens), 1))(*lens)
+        keep = [np.ascontiguousarray(codes, dtype=np.uint32)]
+        args = []
+        for m in (inv_runs, low_runs):
+            m = np.asarray(m)
+            if m.dtype == np.uint32 and m.ndim == 1:            # dense bitmap
+                m = np.ascontiguousarray(m)
+                args += [_ptr(m), -1]
+            else:
+                m = np.ascontiguousarray(m, dtype=np.int64).reshape(-1, 2)
+                args += [_ptr(m), int(m.shape[0])]
+            keep.append(m)
+        self._check(self._lib.frisk_seq_stage_2bit(self._ctx, _ptr(keep[0]), args[0], args[1], args[2], args[3], arr, len(lens),
+                                                   int(piece_bases)))
+        self._staged = (keep, lens)
+
+    def export_2bit(self, pinned=False):
+        """(codes, inv_runs, low_runs) of the resident batch in the 0.25 B/base form."""
+        w32 = self.padded_len // 32
+        codes = self.host_array("codes2", 2 * w32, np.uint32) if pinned else np.empty(2 * w32, np.uint32)
+        pi, pl, ni, nl = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+        self._check(self._lib.frisk_seq_export_2bit(self._ctx, _ptr(codes), C.byref(pi), C.byref(ni), C.byref(pl), C.byref(nl)))
+        return (codes,) + self._take_runs(pi, ni, pl, nl, pinned)
 
     def commit(self, names=None):
         self._check(self._lib.frisk_seq_commit(self._ctx))

@@ -90,6 +90,26 @@ int frisk_seq_load(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* le
 int frisk_seq_stage(frisk_ctx* ctx, const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq);
 int frisk_seq_stage_packed(frisk_ctx* ctx, const uint32_t* codes, const uint32_t* inv, const uint32_t* low,
                            const int64_t* lens, int32_t n_seq);
+/* The 0.25 B/base upload form - the north star's "2-bit-packed and streamed to HBM", SURVEY.md 8(d)'s algorithmic bytes: only
+ * the 2-bit codes travel densely (2 * P / 32 words, P = frisk_padded_len_of(lens, n_seq), library layout: scaffold s at padded
+ * positions [off, off + len), one PAD behind it, 16 bases per word, first base most significant); the two masks travel as run
+ * lists - n_inv / n_low pairs [begin, end) of padded positions, ascending and disjoint: inv = letters other than ACGTacgt,
+ * low = lowercase acgt - and are expanded to the bitmaps on the device; PADs are the library's business.  n_inv (n_low) < 0:
+ * the argument is the dense bitmap instead (P / 32 words, PAD bits clear) - for an assembly with more runs than bitmap words.
+ * The codes cross PCIe in pieces of piece_bases positions (0: the library's default, 64 Mbases = 16 MB) with an event behind
+ * each: frisk_seq_commit does not wait for them, and frisk_profile_add(-1, -1) on the committed batch counts piece i while
+ * piece i + 1 is on its way, so that of phase A only the last piece's kernel follows the upload.  Any other use of the batch
+ * waits (on the device) for the last piece.  Replaces, with frisk_pack_2bit, the hand-off of scaffold strings from iterFasta
+ * (L139-164) to computeKmers (L297) and crawlGenome (L203).  Caller keeps the arrays alive as for frisk_seq_stage. */
+int frisk_seq_stage_2bit(frisk_ctx* ctx, const uint32_t* codes, const int64_t* inv_runs, int64_t n_inv, const int64_t* low_runs,
+                         int64_t n_low, const int64_t* lens, int32_t n_seq, int64_t piece_bases);
+/* Host-only (multi-threaded): scaffolds as ASCII -> that form.  codes: caller's buffer of 2 * P / 32 words (page-locked memory
+ * makes the upload asynchronous); *inv_runs / *low_runs: malloc'd by the library (frisk_free), n pairs each. */
+int frisk_pack_2bit(const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq, uint32_t* codes, int64_t** inv_runs,
+                    int64_t* n_inv, int64_t** low_runs, int64_t* n_low);
+int64_t frisk_padded_len_of(const int64_t* lens, int32_t n_seq);   /* P: sum(len + 1) rounded up to 32 (32 for an empty batch); -1: bad lengths */
+/* The resident batch in that form (the CLI's sequence cache): codes into the caller's buffer, run lists malloc'd (frisk_free). */
+int frisk_seq_export_2bit(frisk_ctx* ctx, uint32_t* codes, int64_t** inv_runs, int64_t* n_inv, int64_t** low_runs, int64_t* n_low);
 int frisk_seq_commit(frisk_ctx* ctx);
 /* Packed arrays of the resident batch: codes 2 * P / 32 words, inv and low P / 32 words each, P = frisk_seq_padded_len(). */
 int frisk_seq_export_packed(frisk_ctx* ctx, uint32_t* codes, uint32_t* inv, uint32_t* low);
@@ -214,6 +234,19 @@ char* frisk_format_rows(int64_t n_rows, const char* const* names, const int32_t*
                         const int64_t* stop, const uint8_t* kld_is_int0, const double* kld, const double* gc,
                         const double* pi, const double* si, const double* cri, int64_t* out_len);
 void frisk_free(void* ptr);
+
+/* Host-only: the 2-state, one-feature Gaussian HMM that segments the KLD track - what the reference asks of hmmlearn's
+ * GaussianHMM(n_components=2, covariance_type="full") at L1539-1541 (fit on all non-NaN window scores stacked as one sequence)
+ * and at L769 inside hmm2BED (Viterbi path per scaffold).  The model is the one frisk_amd/hmm.py documents (Baum-Welch with
+ * hmmlearn's default priors, deterministic 2-means start, state 0 = the lower mean); this is its multi-threaded form for the
+ * 3 M windows of a GRCh38-sized run.  frisk_hmm_fit: x[n] finite; n_iter / tol / min_covar / covars_prior as hmmlearn's
+ * arguments (10, 1e-2, 1e-3, 1e-2); outputs means[2], covars[2], startprob[2], transmat[4] (row-major), the log-likelihood of
+ * the last E step and the number of EM rounds run (nullable).  frisk_hmm_viterbi: n_seg sequences x[seg_off[s] .. seg_off[s+1])
+ * decoded independently into states[] (0 / 1), one task per sequence. */
+int frisk_hmm_fit(const double* x, int64_t n, int32_t n_iter, double tol, double min_covar, double covars_prior, double* means,
+                  double* covars, double* startprob, double* transmat, double* loglik, int32_t* iters);
+int frisk_hmm_viterbi(const double* x, const int64_t* seg_off, int32_t n_seg, const double* means, const double* covars,
+                      const double* startprob, const double* transmat, int8_t* states);
 
 /* Page-locked host memory for result buffers: D2H copies into it are asynchronous and run at PCIe rate
  * (pageable buffers work too, at a fraction of it).  Free with frisk_host_free before frisk_destroy. */
