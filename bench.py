@@ -527,6 +527,7 @@ def main(argv=None):
                 "note": "with the ring: one window in %d gathers every position, the others the entering range (inc positions, rounded "
                         "up to the lanes that hold them) and read / park the rest as coalesced doubles" % chunk})(W - KMAX + 1, 16),
             "binding": binding,
+            "allreduce_path": getattr(eng, "allreduce_path", None) if world > 1 else "none (one rank: no collective)",
             **({"rehearsal_on_one_gpu": True} if rehearsal else {}),
             "inclusive": inclusive,
             "cold": cold,

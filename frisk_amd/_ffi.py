@@ -54,6 +54,7 @@ SYMBOLS = [
     ("frisk_profile_export_device", C.c_int, [_P, _P]),
     ("frisk_profile_import_device", C.c_int, [_P, _P]),
     ("frisk_profile_device_view", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("frisk_profile_allreduce", C.c_int, [_P, _P]),
     ("frisk_profile_export_host", C.c_int, [_P, _P]),
     ("frisk_profile_import_host", C.c_int, [_P, _P]),
     ("frisk_profile_finalize", C.c_int, [_P]),

@@ -245,12 +245,12 @@ def _main(argv=None):
     index_writers = []
 
     # Sharded jobs: a rank with a seek index of the FASTA (fasta_index.h; in --tempDir, or beside the file) copies the bytes of
-    # its tiles instead of parsing all of it.  --recalc (store_false: recompute) ignores an index of ours; where a rank had to
+    # its tiles instead of parsing all of it.  --recalc (store_false: recompute) ignores every index; where a rank had to
     # parse, rank 0 writes the index beside the other caches for the next run - in the background, it is not needed by this one.
     def _shard_index(fasta):
         from .fasta import fastaIndexPaths
         paths = fastaIndexPaths(fasta, args.tempDir)
-        return paths if args.recalc else paths[2:]
+        return paths if args.recalc else []         # (--recalc: no index at all, not ours and not a foreign <fasta>.fai)
 
     def _note_shard_load(fasta):
         if hp.engine.shard_index is not None:
@@ -362,12 +362,15 @@ def _main(argv=None):
     threshold, _bins = pp.setKLDThresh(args, logKLD)
     threshold = float(np.ravel(threshold)[0])
     log.info("log10(KLD) threshold = %s", threshold)
+    clock.lap("KLD threshold")
     if args.hmmKLD:                                                     # L1537-1548
         from .hmm import hmm2BED, hmmBED2GFF
         intervals, _model = hmm2BED(table)
         with open(os.path.join(args.tempDir, args.hmmOutfile), "w") as fh:
-            for line in hmmBED2GFF(intervals):
-                fh.write(line)
+            fh.writelines(hmmBED2GFF(intervals))
+        log.info("HMM segmentation: %s state features (fit: %s EM rounds, log-likelihood %s)", len(intervals),
+                 getattr(_model, "n_iter_", "?"), getattr(_model, "loglik_", "?"))
+        clock.lap("HMM segmentation + GFF")
     if args.runProjection:                                              # L1556-1596: counts for the projection
         from .fasta import readFasta
         from .projection import symmetricCounts
@@ -397,6 +400,6 @@ def _main(argv=None):
                     fh.write(line)
         else:
             log.info("No RIP features detected.")
-    clock.lap("thresholds + features")
+    clock.lap("anomaly / RIP features + GFF")
     clock.report()
     return 0

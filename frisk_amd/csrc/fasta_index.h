@@ -150,7 +150,7 @@ inline bool read_index(const char* path, const MappedFile& f, std::vector<FaiEnt
     if (bad) { why = std::string("malformed index ") + path; return false; }
     if (!stamped) {         // a foreign .fai: not older than the file it describes
         const int64_t mt = have_stat ? int64_t(sb.st_mtim.tv_sec) * 1000000000ll + int64_t(sb.st_mtim.tv_nsec) : 0;
-        if (mt < f.mtime_ns) { why = "the index is older than the FASTA file"; return false; }
+        if (mt <= f.mtime_ns) { why = "the index is not newer than the FASTA file"; return false; }
     }
     if (out.size() > size_t(0x7FFFFFFF)) { why = "too many FASTA records"; return false; }
     // every record where the index says it is: a header line that gives its name ends right before the first base, and the
@@ -177,6 +177,21 @@ inline bool read_index(const char* path, const MappedFile& f, std::vector<FaiEnt
         }
         if (r.len > 0 && (is_space((unsigned char)f.base[r.offset]) || is_space((unsigned char)f.base[last - 1]))) {
             why = "record " + r.name + " does not hold bases where the index says"; return false;
+        }
+        if (!stamped && full > 0) {
+            // a foreign index says nothing about blanks inside lines (samtools counts graphic characters only, the reference's
+            // reader strips whole lines): the terminator behind the first line must be exactly what linewidth - linebases says,
+            // and so must a sample of the interior line ends (and no line may start or end on a blank)
+            const int64_t term = r.linewidth - r.linebases;
+            const int64_t samples = std::min<int64_t>(full, 64);
+            for (int64_t k = 0; k < samples; ++k) {
+                const int64_t ln = k == 0 ? 0 : (full - 1) * k / (samples - 1 > 0 ? samples - 1 : 1);
+                const char* le = f.base + r.offset + ln * r.linewidth + r.linebases;      // behind the line's last base
+                const bool ok_term = term == 1 ? le[0] == '\n' : (le[0] == '\r' && le[1] == '\n');
+                if (!ok_term || is_space((unsigned char)le[-1]) || is_space((unsigned char)le[-r.linebases])) {
+                    why = "record " + r.name + ": a line does not end where the index says"; return false;
+                }
+            }
         }
         prev_end = last;
     }

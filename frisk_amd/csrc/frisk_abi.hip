@@ -2,6 +2,7 @@
 // gfx950 (MI355X) only.  Build: see __graft_entry__.build().
 #include <hip/hip_runtime.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -938,6 +939,14 @@ static int enqueue_mask(frisk_ctx* c, frisk_ctx::Batch& B, uint32_t* d_bits, con
     if (n_runs < 0) {               // dense: P / 32 words in the library's layout (real bases only; PADs are added here)
         int rc = h2d(c, d_bits, runs, w32 * 4, st);
         if (rc) return rc;
+    } else if (size_t(n_runs) * 16 > w32 * 4 + (size_t(1) << 20)) {
+        // more bytes of runs than of bitmap (a sequence that changes case every few bases): expand here, upload densely
+        std::vector<uint32_t> bits(w32, 0u);
+        for (int64_t r = 0; r < n_runs; ++r)
+            for (int64_t p = runs[2 * r]; p < runs[2 * r + 1]; ++p) bits[size_t(p >> 5)] |= 0x80000000u >> (p & 31);
+        int rc = h2d(c, d_bits, bits.data(), w32 * 4, st);
+        if (rc) return rc;
+        HIPC(c, hipStreamSynchronize(st));              // (`bits` is a local)
     } else {
         HIPC(c, hipMemsetAsync(d_bits, 0, w32 * 4, st));
         if (n_runs > 0) {
@@ -1254,6 +1263,32 @@ int frisk_profile_device_view(frisk_ctx* c, void** raw, void** stream) {
     c->profile_final = false;
     return FRISK_OK;
 }
+// The one collective of a multi-GPU job, without torch: RCCL's all-reduce(sum, int64) IN PLACE on the raw profile, on the context's
+// stream.  librccl is not linked: the copy already in the process (PyTorch-ROCm brings its own under the same SONAME) or the
+// system one is resolved on first use, so that a one-GPU process never loads it.
+int frisk_profile_allreduce(frisk_ctx* c, void* rccl_comm) {
+    if (!c) return FRISK_E_ARG;
+    if (!rccl_comm) return FRISK_OK;                    // one GPU: nothing to sum
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*errstr_fn)(int);
+    static allreduce_fn all_reduce = nullptr;
+    static errstr_fn err_string = nullptr;
+    if (!all_reduce) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);           // the instance the caller's communicator came from
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return fail(c, FRISK_E_HIP, std::string("frisk_profile_allreduce: librccl not found: ") + dlerror());
+        all_reduce = reinterpret_cast<allreduce_fn>(dlsym(h, "ncclAllReduce"));
+        err_string = reinterpret_cast<errstr_fn>(dlsym(h, "ncclGetErrorString"));
+        if (!all_reduce) return fail(c, FRISK_E_HIP, "frisk_profile_allreduce: ncclAllReduce not found in librccl");
+    }
+    HIPC(c, hipSetDevice(c->device));
+    const int rc = all_reduce(c->d_raw.p, c->d_raw.p, size_t(c->nprof) + 4, /* ncclInt64 */ 4, /* ncclSum */ 0, rccl_comm, c->stream);
+    if (rc != 0) return fail(c, FRISK_E_HIP, std::string("ncclAllReduce: ") + (err_string ? err_string(rc) : "error"));
+    c->profile_final = false;
+    return FRISK_OK;
+}
+
 int frisk_profile_export_host(frisk_ctx* c, int64_t* dst) {
     if (!c || !dst) return FRISK_E_ARG;
     HIPC(c, hipSetDevice(c->device));
@@ -1678,8 +1713,10 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             const int64_t tail_chunks = (n - cut + chunk8 - 1) / chunk8;
             if (tail_chunks >= wgs && !tune_env("FRISK_TAIL_ANY")) {
                 const int64_t rounds = (tail_chunks + wgs / 2) / wgs;
-                cut = std::min(n - unit, (n - rounds * wgs * chunk8 + unit - 1) / unit * unit);
+                // (a cut is a whole number of units - the kernels number a segment's chunks from its first candidate - and leaves a tail)
+                cut = std::min((n / unit - 1) * unit, (n - rounds * wgs * chunk8 + unit - 1) / unit * unit);
             }
+            if (cut <= 0 || cut >= n || cut % unit != 0) return fail(c, FRISK_E_STATE, "frisk_scan: row segments cut off a unit boundary");
         }
         rc = run_rows(0, 0, cut, c->stream, cut < n);
         if (rc) return rc;

@@ -99,14 +99,15 @@ inline Fit fit(const double* x, int64_t n, int n_iter, double tol, double min_co
     std::vector<double> pm(np_ * 4), edge((np_ + 1) * 2), edgeB((np_ + 1) * 2), pll(np_), acc(np_ * 8);
     double prev = -std::numeric_limits<double>::infinity();
     for (int it = 0; it < n_iter; ++it) {
-        const double lc0 = std::log(m.covars[0]), lc1 = std::log(m.covars[1]);
+        const double lc0 = std::log(m.covars[0]), lc1 = std::log(m.covars[1]), ic0 = 1.0 / m.covars[0], ic1 = 1.0 / m.covars[1];
         const double a00 = m.transmat[0], a01 = m.transmat[1], a10 = m.transmat[2], a11 = m.transmat[3];
         // 1. scaled emissions + the product of every piece's forward steps (row convention: alpha_t = (alpha_{t-1} A) o b_t)
         parallel_for(P, [&](int p) {
             const int64_t a = n * p / P, b = n * (p + 1) / P;
             double m00 = 1, m01 = 0, m10 = 0, m11 = 1, ll = 0;
             for (int64_t t = a; t < b; ++t) {
-                const double l0 = loglik(x[t], m.means[0], m.covars[0], lc0), l1 = loglik(x[t], m.means[1], m.covars[1], lc1);
+                const double d0 = x[t] - m.means[0], d1 = x[t] - m.means[1];
+                const double l0 = -0.5 * ((LOG2PI + lc0) + d0 * d0 * ic0), l1 = -0.5 * ((LOG2PI + lc1) + d1 * d1 * ic1);
                 const double mx = std::max(l0, l1);
                 const double b0 = std::exp(l0 - mx), b1 = std::exp(l1 - mx);
                 B[size_t(t) * 2] = b0; B[size_t(t) * 2 + 1] = b1;
@@ -147,13 +148,17 @@ inline Fit fit(const double* x, int64_t n, int n_iter, double tol, double min_co
                 A[0] = v0; A[1] = v1;
                 t = 1;
             } else { v0 = edge[size_t(p) * 2]; v1 = edge[size_t(p) * 2 + 1]; }
+            double prod = 1.0;                                      // the scales, four to a logarithm (each is >= the smallest transition
+            int held = 0;                                           // probability: one of the two scaled emissions is exactly 1)
             for (; t < b; ++t) {
                 const double w0 = (v0 * a00 + v1 * a10) * B[size_t(t) * 2], w1 = (v0 * a01 + v1 * a11) * B[size_t(t) * 2 + 1];
-                const double s = w0 + w1;
-                ll += std::log(s);
-                v0 = w0 / s; v1 = w1 / s;
+                const double s = w0 + w1, r = 1.0 / s;
+                prod *= s;
+                if (++held == 4 || prod < 1e-200) { ll += std::log(prod); prod = 1.0; held = 0; }
+                v0 = w0 * r; v1 = w1 * r;
                 A[size_t(t) * 2] = v0; A[size_t(t) * 2 + 1] = v1;
             }
+            ll += std::log(prod);
             pll[size_t(p)] += ll;
         });
         double ll = 0;
@@ -195,8 +200,8 @@ inline Fit fit(const double* x, int64_t n, int n_iter, double tol, double min_co
                 const double al0 = A[size_t(t) * 2], al1 = A[size_t(t) * 2 + 1];
                 // posterior of window t
                 double g0 = al0 * be0, g1 = al1 * be1;
-                const double gs = g0 + g1;
-                g0 /= gs; g1 /= gs;
+                const double gr = 1.0 / (g0 + g1);
+                g0 *= gr; g1 *= gr;
                 A[size_t(t) * 2] = g0; A[size_t(t) * 2 + 1] = g1;
                 g0s += g0; g1s += g1; gx0 += g0 * x[t]; gx1 += g1 * x[t];
                 if (t == 0) break;
@@ -205,12 +210,12 @@ inline Fit fit(const double* x, int64_t n, int n_iter, double tol, double min_co
                 // forward vector of window t-1: still in A inside the piece; the last window of the piece before belongs to another
                 // task's walk (which turns it into a posterior) - its forward vector is the edge this piece started from
                 const double p0 = t > a ? A[size_t(t - 1) * 2] : edge[size_t(p) * 2], p1 = t > a ? A[size_t(t - 1) * 2 + 1] : edge[size_t(p) * 2 + 1];
-                double e00 = p0 * a00 * b0, e01 = p0 * a01 * b1, e10 = p1 * a10 * b0, e11 = p1 * a11 * b1;
-                const double es = e00 + e01 + e10 + e11;
-                x00 += e00 / es; x01 += e01 / es; x10 += e10 / es; x11 += e11 / es;
-                double nb0 = a00 * b0 + a01 * b1, nb1 = a10 * b0 + a11 * b1;
-                const double bs = nb0 + nb1;
-                be0 = nb0 / bs; be1 = nb1 / bs;
+                const double e00 = p0 * a00 * b0, e01 = p0 * a01 * b1, e10 = p1 * a10 * b0, e11 = p1 * a11 * b1;
+                const double er = 1.0 / (e00 + e01 + e10 + e11);
+                x00 += e00 * er; x01 += e01 * er; x10 += e10 * er; x11 += e11 * er;
+                const double nb0 = a00 * b0 + a01 * b1, nb1 = a10 * b0 + a11 * b1;
+                const double br = 1.0 / (nb0 + nb1);
+                be0 = nb0 * br; be1 = nb1 * br;
             }
             double* q = &acc[size_t(p) * 8];
             q[0] = g0s; q[1] = g1s; q[2] = gx0; q[3] = gx1; q[4] = x00; q[5] = x01; q[6] = x10; q[7] = x11;

@@ -239,6 +239,33 @@ def _gather_table(dist, group, rank, world, res, names, rip):
     return table, bool(flag[0])
 
 
+def check_same_records(engine, names, group=None):
+    """Every rank of a sharded job loads its tiles by itself - through a seek index or by parsing (load_fasta_shard) - and
+    plans its windows from the record table it ended up with.  Ranks whose tables differ (an index that disagrees with the
+    parser, a file that changed between two ranks' reads) would silently duplicate or drop rows: compare a digest of
+    (record count, names, lengths) over the ranks with one tiny all-reduce and raise on every rank when it differs."""
+    import hashlib
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    import torch
+    h = hashlib.sha256()
+    lens = [int(x) for x in engine.seq_lens]
+    for nm, ln in zip(names, lens):
+        h.update(nm.encode("utf-8", "replace") + b"\0" + str(ln).encode() + b"\0")
+    d = h.digest()
+    sig = [len(lens), sum(lens)] + [int.from_bytes(d[8 * i:8 * i + 8], "little") >> 1 for i in range(3)]
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    lo = torch.tensor(sig, dtype=torch.int64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not bool(torch.equal(lo, hi)):
+        raise RuntimeError("the ranks of this job read different record tables from the FASTA (%d records, %d bases on rank %d): "
+                           "a seek index that disagrees with the file, or a file that changed during the run - "
+                           "remove the index (--recalc) and run again" % (sig[0], sig[1], dist.get_rank(group)))
+
+
 def profile_sharded(engine, host_path, w, inc, mask_host=False, scaffolds_all=False, group=None, index=None):
     """Phase A of one job on this rank (computeKmers genomeMode, L1442): keep the rank's tiles of the host FASTA resident,
     count the k-mers that start in the positions it owns, join the ONE all-reduce, finalise.  Every rank ends with the whole
@@ -248,6 +275,7 @@ def profile_sharded(engine, host_path, w, inc, mask_host=False, scaffolds_all=Fa
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     names, _ = engine.load_fasta_shard(host_path, w, inc, rank, world, scaffolds_all, index=index)
+    check_same_records(engine, names, group)
     engine.profile_reset()
     engine.profile_add(mask_host=mask_host)
     engine.profile_allreduce(group)
@@ -264,6 +292,7 @@ def scan_sharded(engine, query_path, w, inc, rip=False, scaffolds_all=False, gro
     names = resident_names
     if names is None:
         names, _ = engine.load_fasta_shard(query_path, w, inc, rank, world, scaffolds_all, index=index)
+        check_same_records(engine, names, group)
     res = engine.scan(w, inc, rip=rip, scaffolds_all=scaffolds_all)
     return _gather_table(dist, group, rank, world, res, names, rip)
 

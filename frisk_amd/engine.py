@@ -314,37 +314,88 @@ class Engine:
         assert raw.shape == (self.nprof + 4,)
         self._check(self._lib.frisk_profile_import_host(self._ctx, _ptr(raw)))
 
-    def profile_allreduce(self, group=None, force=False):
-        """Sum the raw (linear) profile over all ranks: ONE all-reduce (RCCL when the process group's
-        backend is nccl; gloo works too for the CPU rehearsal of the multi-rank path).  force=True runs the
-        collective even in a one-rank group (tests)."""
+    def profile_allreduce(self, group=None, force=False, comm=None):
+        """Sum the raw (linear) profile over all ranks: the ONE collective of a job.  `self.allreduce_path` names what ran:
+          rccl_direct               comm = an ncclComm_t (int / c_void_p): the library's own frisk_profile_allreduce, no torch
+          in_place_external_stream  torch.distributed with the nccl (= RCCL) backend, IN PLACE on the library's buffer under the
+                                    context's stream - no copies, no host wait.  The first use in a group of several ranks is
+                                    CHECKED against the copying path below (one extra all-reduce, once per engine); if
+                                    ProcessGroupNCCL rejects the zero-copy view or the external stream, or the results
+                                    differ, the engine falls back for good
+          export_import_copy        export to a torch tensor -> all_reduce -> import (two D2D copies, host waits)
+          host_gloo                 any backend that reduces CPU tensors (the CPU rehearsal of the multi-rank path)
+        force=True runs the collective even in a one-rank group (tests)."""
+        if comm is not None:
+            self._check(self._lib.frisk_profile_allreduce(self._ctx, C.c_void_p(int(getattr(comm, "value", comm) or 0))))
+            self.allreduce_path = "rccl_direct"
+            return
         import torch
         import torch.distributed as dist
         if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
             return
         n = self.nprof + 4
-        if dist.get_backend(group) == "nccl":
-            # in place, on the context's own stream: the library's raw-profile buffer as a torch tensor, the collective issued
-            # under the context's stream (ProcessGroupNCCL chains its own stream to the current one with events, both ways) -
-            # profile_add -> all-reduce -> finalize stay one chain of enqueued work, the host never waits
+        if dist.get_backend(group) != "nccl":
+            from .distributed import allreduce_raw_host
+            self.profile_set_raw(allreduce_raw_host(self.profile_raw(), group))
+            self.allreduce_path = "host_gloo"
+            return
+        dev = torch.device("cuda", self.device)
+
+        def copying():
+            t = torch.empty(n, dtype=torch.int64, device=dev)
+            self._check(self._lib.frisk_profile_export_device(self._ctx, C.c_void_p(t.data_ptr())))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(dev)
+            self._check(self._lib.frisk_profile_import_device(self._ctx, C.c_void_p(t.data_ptr())))
+            return t
+
+        def in_place():
+            # the library's raw-profile buffer as a torch tensor, the collective issued under the context's stream
+            # (ProcessGroupNCCL chains its own stream to the current one with events, both ways): profile_add -> all-reduce ->
+            # finalize stay one chain of enqueued work.  The view and the stream wrapper are kept from step to step.
             raw, stream = C.c_void_p(), C.c_void_p()
             self._check(self._lib.frisk_profile_device_view(self._ctx, C.byref(raw), C.byref(stream)))
-
-            # (the tensor view and the stream wrapper are kept from step to step: the buffer and the stream belong to the context)
             key = (int(raw.value), int(stream.value or 0), n)
             kept = getattr(self, "_allreduce_keep", None)
             if kept is None or kept[0] != key:
                 class _View:
                     __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (key[0], False), "version": 2}
-                dev = torch.device("cuda", self.device)
                 kept = (key, torch.as_tensor(_View(), device=dev), torch.cuda.ExternalStream(key[1], device=dev))
                 self._allreduce_keep = kept
             _, t, ext = kept
             with torch.cuda.stream(ext):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        else:
-            from .distributed import allreduce_raw_host
-            self.profile_set_raw(allreduce_raw_host(self.profile_raw(), group))
+            return t
+
+        mode = getattr(self, "_allreduce_mode", None)
+        if mode == "copy":
+            copying()
+            self.allreduce_path = "export_import_copy"
+            return
+        if mode == "in_place" or dist.get_world_size(group) == 1:
+            in_place()
+            self.allreduce_path = "in_place_external_stream"
+            return
+        # first use with several ranks: both paths on the same input, compared on the device; every rank takes the same decision
+        import logging
+        before = torch.empty(n, dtype=torch.int64, device=dev)
+        self._check(self._lib.frisk_profile_export_device(self._ctx, C.c_void_p(before.data_ptr())))
+        ok = 1
+        try:
+            fast = in_place().clone()
+            torch.cuda.synchronize(dev)
+        except Exception as err:                 # noqa: BLE001 - whatever ProcessGroupNCCL objects to, the copying path does not need
+            logging.getLogger("frisk_amd").warning("in-place all-reduce refused (%s): copying path from now on", err)
+            ok, fast = 0, None
+        self._check(self._lib.frisk_profile_import_device(self._ctx, C.c_void_p(before.data_ptr())))
+        slow = copying()
+        if ok and not bool(torch.equal(fast, slow)):
+            logging.getLogger("frisk_amd").warning("in-place all-reduce disagrees with the copying path: copying path from now on")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self._allreduce_mode = "in_place" if int(flag.item()) == 1 else "copy"
+        self.allreduce_path = "export_import_copy (first use: in-place path %s)" % ("verified" if self._allreduce_mode == "in_place" else "rejected")
 
     def profile_finalize(self):
         self._check(self._lib.frisk_profile_finalize(self._ctx))

@@ -53,7 +53,7 @@ def mapsToProfile(maps, kMin, kMax):
 
 
 
-SEQ_CACHE_MAGIC = b"FRISK2B1"
+SEQ_CACHE_MAGIC = b"FRISK2B2"
 
 
 def seqCachePath(cache_dir, fasta):
@@ -65,19 +65,29 @@ def _source_stamp(fasta):
     return [int(st.st_size), int(st.st_mtime_ns)]
 
 
-def writeSeqCache(cache, fasta, names, lens, codes, inv, low):
-    """<magic><u64 header length><json header><codes><inv><low> - written to a temporary name and renamed."""
+def _padded_len(lens):
+    p = (sum(int(n) + 1 for n in lens) + 31) // 32 * 32
+    return p or 32
+
+
+def writeSeqCache(cache, fasta, names, lens, codes, inv_runs, low_runs):
+    """<magic><u64 header length><json header><codes: uint32><inv runs: int64 pairs><low runs: int64 pairs> - the 0.25 B/base
+    form frisk_seq_stage_2bit uploads (2-bit codes + run lists of the two masks) - written to a temporary name and renamed."""
     import json
+    inv_runs = np.ascontiguousarray(inv_runs, dtype=np.int64).reshape(-1, 2)
+    low_runs = np.ascontiguousarray(low_runs, dtype=np.int64).reshape(-1, 2)
     head = json.dumps({"source": os.path.abspath(fasta), "stamp": _source_stamp(fasta), "names": names, "lens": [int(x) for x in lens],
-                       "words": [int(codes.size), int(inv.size), int(low.size)]}).encode()
+                       "words": int(codes.size), "runs": [int(inv_runs.shape[0]), int(low_runs.shape[0])]}).encode()
+    head += b" " * (-(16 + len(head)) % 8)              # the arrays start on a multiple of 8 bytes
     tmp = cache + ".tmp%d" % os.getpid()
     try:
         with open(tmp, "wb") as fh:
             fh.write(SEQ_CACHE_MAGIC)
             fh.write(np.uint64(len(head)).tobytes())
             fh.write(head)
-            for a in (codes, inv, low):
-                np.ascontiguousarray(a, dtype=np.uint32).tofile(fh)
+            np.ascontiguousarray(codes, dtype=np.uint32).tofile(fh)
+            inv_runs.tofile(fh)
+            low_runs.tofile(fh)
         os.replace(tmp, cache)
     except OSError:
         try:
@@ -87,26 +97,37 @@ def writeSeqCache(cache, fasta, names, lens, codes, inv, low):
 
 
 def readSeqCache(cache, fasta):
-    """(names, lens, codes, inv, low) - the three arrays memory-mapped - or None when there is no cache for this very file
-    (size and modification time of the FASTA are part of the cache)."""
+    """(names, lens, codes, inv_runs, low_runs) - the three arrays memory-mapped - or None when there is no cache for this very
+    file: the cache names the FASTA it was made from (absolute path, size, modification time), and its array sizes must be
+    the ones the record lengths imply - a truncated, edited or foreign file is not handed to the uploader."""
     import json
     try:
         with open(cache, "rb") as fh:
             if fh.read(8) != SEQ_CACHE_MAGIC:
                 return None
             n = int(np.frombuffer(fh.read(8), dtype=np.uint64)[0])
+            if n > (1 << 31):
+                return None
             head = json.loads(fh.read(n).decode())
             off = 16 + n
-        if head.get("stamp") != _source_stamp(fasta):
+        if head.get("stamp") != _source_stamp(fasta) or head.get("source") != os.path.abspath(fasta):
             return None
-        arrays = []
-        for words in head["words"]:
-            arrays.append(np.memmap(cache, dtype=np.uint32, mode="r", offset=off, shape=(int(words),)))
-            off += 4 * int(words)
-        if os.path.getsize(cache) != off:
+        lens = [int(x) for x in head["lens"]]
+        names = list(head["names"])
+        words, (n_inv, n_low) = int(head["words"]), (int(x) for x in head["runs"])
+        P = _padded_len(lens)
+        if len(names) != len(lens) or min(lens, default=0) < 0 or words != 2 * P // 32 or n_inv < 0 or n_low < 0:
             return None
-        return head["names"], head["lens"], arrays[0], arrays[1], arrays[2]
-    except (OSError, ValueError, KeyError):
+        if os.path.getsize(cache) != off + 4 * words + 16 * (n_inv + n_low):
+            return None
+        codes = np.memmap(cache, dtype=np.uint32, mode="r", offset=off, shape=(words,))
+        off += 4 * words
+        runs = []
+        for k in (n_inv, n_low):
+            runs.append(np.memmap(cache, dtype=np.int64, mode="r", offset=off, shape=(k, 2)) if k else np.zeros((0, 2), np.int64))
+            off += 16 * k
+        return names, lens, codes, runs[0], runs[1]
+    except (OSError, ValueError, KeyError, TypeError):
         return None
 
 
@@ -160,8 +181,9 @@ class HotPath:
         self._resident = None       # path of the FASTA whose scaffolds are on the device
         self.names = []
         # packed-sequence cache (beside the reference's pickle caches in --tempDir): <fasta basename>.frisk2bit holds the 2-bit
-        # codes and the two bitmaps exactly as they lie in HBM, so a later run on the same file neither parses (nor inflates) it
-        # nor packs it, and PCIe carries 0.5 B per base.  use_cache=False (--recalc given): ignore and rewrite it.
+        # codes as they lie in HBM and the two masks as run lists, so a later run on the same file neither parses (nor inflates)
+        # it nor packs it, PCIe carries 0.25 B per base, and phase A follows the upload piece by piece (frisk_seq_stage_2bit).
+        # use_cache=False (--recalc given): ignore and rewrite it.
         self.cache_dir, self.use_cache = cache_dir, use_cache
         self.loaded_from_cache = False
         self._writer = None
@@ -183,8 +205,8 @@ class HotPath:
         if cache and self.use_cache:
             got = readSeqCache(cache, path)
             if got is not None:
-                names, lens, codes, inv, low = got
-                self.engine.stage_packed(codes, inv, low, lens)
+                names, lens, codes, inv_runs, low_runs = got
+                self.engine.stage_2bit(codes, inv_runs, low_runs, lens)
                 self.engine.commit(names)
                 self.names, self._resident, self.loaded_from_cache = names, path, True
                 return
@@ -192,10 +214,10 @@ class HotPath:
         self._resident = path
         if cache:
             self._join_writer()
-            codes, inv, low = self.engine.export_packed()
+            codes, inv_runs, low_runs = self.engine.export_2bit()
             import threading                                # (the file is written while the profile and the scan run)
             self._writer = threading.Thread(target=writeSeqCache, args=(cache, path, list(self.names), list(self.engine.seq_lens),
-                                                                        codes, inv, low), daemon=False)
+                                                                        codes, inv_runs, low_runs), daemon=False)
             self._writer.start()
 
     # phase A -----------------------------------------------------------------------------------

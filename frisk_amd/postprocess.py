@@ -59,6 +59,17 @@ def FDBins(data):
     return int(round(2 * (q75 - q25) * math.pow(len(data), 1.0 / 3.0)))
 
 
+def _py_max(a):
+    """Python's max() over the rows of an array, without the 3 M Python steps: max() keeps its first element until a LARGER one
+    comes (comparisons with NaN are false), so the result is NaN iff the first element is NaN, else the largest non-NaN one."""
+    a = np.asarray(a, dtype=float)
+    flat = a.reshape(a.shape[0], -1)[:, 0] if a.ndim > 1 else a
+    if flat.size == 0:
+        raise ValueError("max() arg is an empty sequence")
+    m = flat[0] if np.isnan(flat[0]) else np.nanmax(flat)
+    return a[0] * 0 + m if a.ndim > 1 else m
+
+
 def otsu(data, optBins):
     """Otsu split of the log10(KLD) histogram, restated from L515-543: the values are scaled by
     -1/max|x| (so they become positive), binned into optBins bins normalised to the tallest bin, and the
@@ -67,7 +78,7 @@ def otsu(data, optBins):
     raw = data
     x = np.atleast_1d(data)
     x = x[~np.isnan(x)]
-    scale = max(abs(x)) * -1.0
+    scale = _py_max(np.abs(x)) * -1.0
     x = x / scale
     hist, edges = np.histogram(x, bins=optBins)
     h = hist * 1.0
@@ -83,7 +94,7 @@ def otsu(data, optBins):
         score = (v1 * q1) + (v2 * q2)
         if score < best:
             best, thresh = score, i
-    return edges[thresh] * max(abs(raw)) * -1.0
+    return edges[thresh] * _py_max(np.abs(raw)) * -1.0         # (max(abs(raw)) of the reference: NaN rows included, as there)
 
 
 def setKLDThresh(args, logKLD):
@@ -133,6 +144,44 @@ def merge_intervals(records, dist=0, ops=("max",), cols=(3,)):
     return merged
 
 
+def _name_ranks(names):
+    """rank of every scaffold NAME in Python's string order (the sort key of L655 / L710), equal names sharing a rank."""
+    order = {nm: r for r, nm in enumerate(sorted(set(names)))}
+    return np.asarray([order[nm] for nm in names], dtype=np.int64)
+
+
+def merge_columns(names, name_rank, start, stop, values, dist=0, ops=("max",), cols=(0,)):
+    """merge_intervals on COLUMNS: rows already sorted by (name, start, stop); name_rank[i] = rank of row i's scaffold name,
+    values = list of float arrays the (op, col) pairs index.  Same features as merge_intervals (tested against it), without a
+    Python step per row: the running end of bedtools' sweep is a running maximum of `stop` inside a scaffold, a feature ends
+    where the next start lies more than `dist` behind it."""
+    n = len(start)
+    if n == 0:
+        return []
+    big = int(max(int(stop.max()), int(start.max()), 0)) + abs(int(dist)) + 2
+    run_end = np.maximum.accumulate(stop.astype(np.int64) + name_rank * big) - name_rank * big
+    brk = np.ones(n, dtype=bool)
+    brk[1:] = (name_rank[1:] != name_rank[:-1]) | (start[1:] - run_end[:-1] > dist)
+    a = np.nonzero(brk)[0]
+    cnt = np.diff(np.concatenate((a, [n])))
+    ends = np.maximum.reduceat(stop, a)
+    summ = []
+    for op, col in zip(ops, cols):
+        v = np.ascontiguousarray(values[col], dtype=np.float64)
+        if op == "max":
+            r = np.maximum.reduceat(v, a)
+        elif op == "min":
+            r = np.minimum.reduceat(v, a)
+        else:
+            r = np.add.reduceat(v, a) / cnt
+            big_groups = np.nonzero(cnt >= 8)[0]          # numpy's mean sums pairwise from 8 elements on: take its value there
+            for g in big_groups.tolist():
+                r[g] = v[a[g]:a[g] + cnt[g]].mean()
+        summ.append(["%.5g" % x for x in r.tolist()])
+    return [(names[i], s0, e0) + tuple(c[k] for c in summ)
+            for k, (i, s0, e0) in enumerate(zip(a.tolist(), start[a].tolist(), ends.tolist()))]
+
+
 def thresholdKLD(table, threshold, args, merge=True):
     """Windows whose log10(KLD) is >= threshold (<= with --findSelf), sorted by (name, start, stop), merged with
     `-d mergeDist -c 4,4,4 -o max,min,mean` (L647-662).  table: list of rows (name, start, stop, KLD, ...).
@@ -142,7 +191,16 @@ def thresholdKLD(table, threshold, args, merge=True):
         with np.errstate(divide="ignore", invalid="ignore"):
             logs = np.log10(kld)
         pick = (logs <= threshold) if getattr(args, "findSelf", False) else (logs >= threshold)
-        chosen = table.rows(np.nonzero(pick & ~np.isnan(kld))[0])
+        idx = np.nonzero(pick & ~np.isnan(kld))[0]
+        if merge and idx.size > 20000 and getattr(args, "mergeDist", 0) >= 0:      # many windows selected (3 M rows, an Otsu cut): sort and merge on the columns
+            rank = _name_ranks(table.names)[table.seq_index[idx]]
+            order = np.lexsort((table.stop[idx], table.start[idx], rank))
+            idx, rank = idx[order], rank[order]
+            nm = [table.names[i] for i in table.seq_index[idx].tolist()]
+            feats = merge_columns(nm, rank, table.start[idx], table.stop[idx], [kld[idx]], dist=getattr(args, "mergeDist", 0),
+                                  ops=("max", "min", "mean"), cols=(0, 0, 0))
+            return feats, _LazyRows(table, idx)
+        chosen = table.rows(idx)
         chosen.sort(key=lambda r: (r[0], r[1], r[2]))
     else:
         rows = [r for r in table if not (isinstance(r[3], float) and r[3] != r[3])]
@@ -158,6 +216,22 @@ def thresholdKLD(table, threshold, args, merge=True):
         fmt = py3_str if os.environ.get("FRISK_FLOAT_REPR", "py2") == "py3" else py2_str    # the table's float text
         feats = [(c, s, e, fmt(v)) for c, s, e, v in recs]
     return feats, chosen
+
+
+class _LazyRows:
+    """The selected rows of a big table, in sorted order, as tuples on demand (the callers of thresholdKLD use them rarely)."""
+
+    def __init__(self, table, idx):
+        self.table, self.idx = table, idx
+
+    def __len__(self):
+        return int(self.idx.size)
+
+    def __iter__(self):
+        return iter(self.table.rows(self.idx))
+
+    def __getitem__(self, k):
+        return self.table.rows(self.idx[k] if isinstance(k, slice) else [self.idx[k]])[0 if not isinstance(k, slice) else slice(None)]
 
 
 def anomaly2GFF(features, args, category="Kmer-anomaly", version=FRISK_VERSION):
@@ -195,10 +269,24 @@ def thresholdRIP(table, args):
         return None
     recs = [(r[0], int(r[1]), int(r[2]), r[3], r[5], r[6], r[7]) for r in basic]
     merged = merge_intervals(recs, dist=0, ops=("max", "min", "max", "min", "max"), cols=(3, 4, 5, 6, 6))
+    # bedtools window -w 0: A and B overlap (half-open BED arithmetic on the given coordinates).  Peaks per scaffold sorted by
+    # start, with the running maximum of their ends: a feature overlaps one iff, among the peaks that start before its end,
+    # some end lies behind its start
+    by = {}
+    for p in peaks:
+        by.setdefault(p[0], []).append((int(p[1]), int(p[2])))
+    idx = {}
+    for nm, lst in by.items():
+        lst.sort()
+        st = np.asarray([x[0] for x in lst], dtype=np.int64)
+        idx[nm] = (st, np.maximum.accumulate(np.asarray([x[1] for x in lst], dtype=np.int64)))
     keep = []
     for f in merged:
-        # bedtools window -w 0: A and B overlap (half-open BED arithmetic on the given coordinates)
-        if any(p[0] == f[0] and int(p[1]) < f[2] and int(p[2]) > f[1] for p in peaks):
+        got = idx.get(f[0])
+        if got is None:
+            continue
+        k = int(np.searchsorted(got[0], f[2], side="left"))        # peaks with start < feature end
+        if k > 0 and got[1][k - 1] > f[1]:
             keep.append(f)
     return keep or None
 

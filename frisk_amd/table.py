@@ -56,7 +56,16 @@ class ScoreTable:
         """From the DataFrame the reference pickles (L1501), incl. the legacy windowKLI column name (L1458-1459)."""
         kcol = "windowKLD" if "windowKLD" in frame.columns else "windowKLI"
         cols = ["name", "start", "stop", kcol, "GC"] + (RIP_COLUMNS if rip else [])
-        return cls.from_rows([tuple(r) for r in frame[cols].itertuples(index=False, name=None)], rip=rip)
+        numeric = all(frame[c].dtype.kind in "iuf" for c in cols[1:])
+        if not numeric:                 # object columns (a frame built row by row, as the reference's: the int 0 of L465 survives there)
+            return cls.from_rows([tuple(r) for r in frame[cols].itertuples(index=False, name=None)], rip=rip)
+        # the frame this package pickles: numeric columns - taken over as arrays (3 M rows: milliseconds instead of seconds)
+        import pandas as pd
+        codes, uniq = pd.factorize(frame["name"], sort=False)          # scaffolds in order of first appearance, as from_rows
+        col = lambda c, dt: frame[c].to_numpy(dtype=dt)                 # noqa: E731
+        return cls([str(u) for u in uniq], codes.astype(np.int32), col("start", np.int64), col("stop", np.int64), col(kcol, np.float64),
+                   col("GC", np.float64), col("PI", np.float64) if rip else None, col("SI", np.float64) if rip else None,
+                   col("CRI", np.float64) if rip else None, None)
 
     # ------------------------------------------------------------------ views
     def __len__(self):

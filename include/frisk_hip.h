@@ -186,6 +186,12 @@ int frisk_profile_import_device(frisk_ctx* ctx, const void* src_device_int64);
  * all-reduce over xGMI, issued under torch.cuda.ExternalStream(*stream) - so that profile_add -> all-reduce -> finalize is
  * one chain of enqueued work.  The call marks the profile as changed (as frisk_profile_import_device does). */
 int frisk_profile_device_view(frisk_ctx* ctx, void** raw, void** stream);
+/* The one exchange step of a multi-GPU job without any framework: RCCL all-reduce(sum, int64) of the raw profile
+ * IN PLACE over `rccl_comm` (an ncclComm_t of the caller's making: one rank per GPU, created with ncclCommInitRank on this
+ * context's device), enqueued on the context's stream - profile_add -> all-reduce -> finalize stay one chain, the host does
+ * not wait.  rccl_comm = NULL: a single GPU, nothing to do.  librccl is resolved at first use (the instance already in the
+ * process if there is one); it is not a link-time dependency of the library. */
+int frisk_profile_allreduce(frisk_ctx* ctx, void* rccl_comm);
 int frisk_profile_export_host(frisk_ctx* ctx, int64_t* dst_host);
 int frisk_profile_import_host(frisk_ctx* ctx, const int64_t* src_host);
 int frisk_profile_finalize(frisk_ctx* ctx);

@@ -44,10 +44,12 @@ class FakeEngine:
             (c0, c1), tiles = plan_tiles(lens, w, inc, scaffolds_all, self.kmax, rank, world)
             self.load([readFastaIndexed(path, index, t["scaf"], t["base0"], t["end"] - t["base0"])[2] for t in tiles])
             self.shard_index = index
+            self.seq_lens = list(lens)
         else:
             names, seqs = readFasta(path)
             (c0, c1), tiles = plan_tiles([len(s) for s in seqs], w, inc, scaffolds_all, self.kmax, rank, world)
             self.load([seqs[t["scaf"]][t["base0"]:t["end"]] for t in tiles])
+            self.seq_lens = [len(s) for s in seqs]
         self.tiles, self.tile_geom = tiles, (w, inc, scaffolds_all)
         return names, (c0, c1)
 

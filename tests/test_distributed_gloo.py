@@ -123,3 +123,37 @@ def test_tile_plan_properties():
         assert prev_end == total and sum(covered) == total
         for o in owned:
             assert np.all(o == 1)
+
+
+def _run_mismatch(rank, world, port, out_path):
+    import torch.distributed as dist
+    from fake_engine import FakeEngine
+    from frisk_amd.distributed import check_same_records
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    eng = FakeEngine(1, 4)
+    names = ["a", "b"]
+    eng.seq_lens = [100, 200]
+    check_same_records(eng, names)                          # the same table everywhere: silent
+    eng.seq_lens = [100, 200 + rank]                        # rank 1 read another length for record b
+    try:
+        check_same_records(eng, names)
+        verdict = "silent"
+    except RuntimeError as err:
+        verdict = "raised: " + str(err)[:60]
+    with open("%s.%d" % (out_path, rank), "w") as fh:
+        fh.write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_record_tables_fail_loudly(tmp_path):
+    """every rank decides by itself whether it loads its tiles through an index or by parsing; if the record tables
+    they end with differ, window planning differs and rows would be duplicated or lost - the job must stop on EVERY rank."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "verdict")
+    mp.spawn(_run_mismatch, args=(2, port, out), nprocs=2, join=True)
+    for r in range(2):
+        assert open("%s.%d" % (out, r)).read().startswith("raised: the ranks of this job read different record tables")

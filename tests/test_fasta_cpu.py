@@ -100,7 +100,10 @@ def test_large_record_buffer_paths(tmp_path):
 
 def test_packed_sequence_cache_file_roundtrip(tmp_path):
     """The .frisk2bit file (frisk_amd/hotpath.py): what was written comes back memory-mapped, and only for the very FASTA it
-    was made from (size and modification time are part of the cache)."""
+    was made from (path, size and modification time are part of the cache) and only when its array sizes are the ones its
+    record lengths imply (a truncated, edited or foreign cache must never reach the uploader)."""
+    import json
+    import shutil
     import numpy as np
     from frisk_amd.hotpath import readSeqCache, seqCachePath, writeSeqCache
     fa = tmp_path / "g.fa"
@@ -108,17 +111,38 @@ def test_packed_sequence_cache_file_roundtrip(tmp_path):
     cache = seqCachePath(str(tmp_path), str(fa))
     assert cache.endswith("g.fa.frisk2bit")
     rng = np.random.default_rng(1)
-    codes, inv, low = (rng.integers(0, 2 ** 32, size=n, dtype=np.uint32) for n in (8, 4, 4))
+    codes = rng.integers(0, 2 ** 32, size=2, dtype=np.uint32)         # lens 10 + 2: P = 32, two code words
+    inv, low = np.array([[4, 6]], np.int64), np.array([[6, 10]], np.int64)
     writeSeqCache(cache, str(fa), ["a", "b"], [10, 2], codes, inv, low)
     names, lens, c2, i2, l2 = readSeqCache(cache, str(fa))
     assert names == ["a", "b"] and lens == [10, 2]
     assert np.array_equal(c2, codes) and np.array_equal(i2, inv) and np.array_equal(l2, low)
+    writeSeqCache(cache, str(fa), ["a", "b"], [10, 2], codes, np.zeros((0, 2), np.int64), low)        # no N runs at all
+    assert readSeqCache(cache, str(fa))[3].shape == (0, 2)
+    # the same file under another path (the cache is keyed by basename): refused
+    other = tmp_path / "elsewhere"
+    other.mkdir()
+    shutil.copy2(str(fa), str(other / "g.fa"))
+    assert readSeqCache(cache, str(other / "g.fa")) is None
+    # array sizes that do not follow from the lengths: refused (the uploader derives its copy sizes from the lengths)
+    writeSeqCache(cache, str(fa), ["a", "b"], [10, 40], codes, inv, low)
+    assert readSeqCache(cache, str(fa)) is None
+    writeSeqCache(cache, str(fa), ["a"], [10, 2], codes, inv, low)
+    assert readSeqCache(cache, str(fa)) is None
+    writeSeqCache(cache, str(fa), ["a", "b"], [10, 2], codes, inv, low)
+    assert readSeqCache(cache, str(fa)) is not None
     fa.write_text(">a\nACGTNNacgtA\n>b\nAC\n")               # another file now
     assert readSeqCache(cache, str(fa)) is None
     assert readSeqCache(str(tmp_path / "none.frisk2bit"), str(fa)) is None
     with open(cache, "r+b") as fh:                            # truncated file
         fh.truncate(40)
+    assert readSeqCache(cache, str(fa)) is None
     writeSeqCache(cache, str(fa), ["a", "b"], [11, 2], codes, inv, low)
+    assert readSeqCache(cache, str(fa)) is not None
     with open(cache, "r+b") as fh:
         fh.truncate(os.path.getsize(cache) - 4)
+    assert readSeqCache(cache, str(fa)) is None
+    # an older format's magic
+    with open(cache, "wb") as fh:
+        fh.write(b"FRISK2B1" + np.uint64(2).tobytes() + json.dumps({}).encode())
     assert readSeqCache(cache, str(fa)) is None

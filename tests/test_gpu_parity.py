@@ -278,8 +278,10 @@ def test_full_size_properties(shape):
 
 
 def test_rccl_allreduce_path_single_rank():
-    """The nccl(=RCCL) branch of Engine.profile_allreduce: export to a torch tensor, all_reduce(int64, sum),
-    import - exercised in a one-rank process group (the 8-GPU run is the driver's)."""
+    """The nccl(=RCCL) branch of Engine.profile_allreduce in a one-rank process group (the 8-GPU run is the driver's): the
+    all-reduce runs IN PLACE on the library's raw-profile buffer (zero-copy tensor view) under the context's HIP stream
+    (torch.cuda.ExternalStream); the copying path (export -> all_reduce -> import), which a job falls back to when
+    ProcessGroupNCCL refuses the view or the first-use comparison fails, gives the same profile."""
     import torch.distributed as dist
     seqs = synth_seqs([40000, 7000], 13, n_frac=0.05)
     with make_engine(1, 8) as e:
@@ -289,10 +291,49 @@ def test_rccl_allreduce_path_single_rank():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1)
         try:
             e.profile_allreduce(force=True)
+            assert e.allreduce_path == "in_place_external_stream"
+            assert np.array_equal(e.profile_raw(), before)
+            e._allreduce_mode = "copy"                       # what a failed first-use check leaves behind
+            e.profile_allreduce(force=True)
+            assert e.allreduce_path == "export_import_copy"
         finally:
             dist.destroy_process_group()
         assert np.array_equal(e.profile_raw(), before)
         e.profile_finalize()
+        from oracle import frisk_oracle_np as N
+        sym, tl, ex, nn = e.profile_get()
+        osym, ometa = N.genome_profile(seqs, 1, 8)
+        assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
+
+
+def test_library_allreduce_over_a_raw_rccl_communicator():
+    """frisk_profile_allreduce(ctx, ncclComm_t): the one collective without torch.distributed - a one-rank communicator made with
+    ncclGetUniqueId / ncclCommInitRank through ctypes ("RCCL communicator is created by the python side and passed
+    opaquely"), the all-reduce enqueued on the context's stream between profile_add and finalize.  NULL = single GPU, no-op."""
+    import ctypes as C
+    seqs = synth_seqs([30000, 9000], 14, n_frac=0.05, lower_frac=0.1)
+    with make_engine(1, 8) as e:
+        e.load(seqs)
+        e.profile_reset(); e.profile_add()
+        before = e.profile_raw()
+        e.profile_allreduce(comm=0)                          # NULL communicator
+        assert e.allreduce_path == "rccl_direct" and np.array_equal(e.profile_raw(), before)
+        rccl = C.CDLL("librccl.so.1")
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid, comm = UniqueId(), C.c_void_p()
+        rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+        assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+        try:
+            e.profile_allreduce(comm=comm)
+            e.profile_finalize()                             # enqueued behind the collective, no host wait in between
+            assert np.array_equal(e.profile_raw(), before)
+        finally:
+            rccl.ncclCommDestroy(comm)
         from oracle import frisk_oracle_np as N
         sym, tl, ex, nn = e.profile_get()
         osym, ometa = N.genome_profile(seqs, 1, 8)

@@ -109,3 +109,46 @@ def test_cli_surface_equals_reference():
     assert os.path.basename(makePicklePath(a, "window")) == doc["window_pickle_basename"]
     # --recalc / --recalcWin are store_false: PASSING them forces recomputation
     assert a.recalc is True and parser.parse_args(["-H", "h", "--recalc"]).recalc is False
+
+
+def test_column_merge_equals_the_row_merge():
+    """thresholdKLD's path for big tables (sort + bedtools-style merge on numpy columns) against the row-by-row restatement:
+    same features, same text, for random tables with duplicate names, overlapping / book-ended / nested windows and merge
+    distances 0 and > 0; and the reload of a pickled frame (ScoreTable.from_frame on columns) against from_rows."""
+    from types import SimpleNamespace
+    from frisk_amd import postprocess as pp
+    from frisk_amd.table import ScoreTable
+    rng = np.random.default_rng(8)
+    for trial in range(6):
+        names = ["chr%d" % i for i in rng.permutation(12)] + ["chr3"]            # a name twice: grouped by NAME
+        rows = []
+        for s, nm in enumerate(names):
+            pos = 1
+            for _ in range(int(rng.integers(2500, 3500))):
+                pos += int(rng.integers(0, 4)) * 500
+                w = int(rng.choice([1000, 5000, 200]))
+                rows.append((nm, pos, pos + w - 1, float(abs(rng.normal(0.05, 0.05)) + 1e-4), 0.5))
+        table = ScoreTable.from_rows(rows, rip=False)
+        thr = float(np.log10(np.percentile(table.kld, 30)))
+        for dist in (0, 700):
+            a = SimpleNamespace(findSelf=False, mergeDist=dist)
+            fast, sel = pp.thresholdKLD(table, thr, a, merge=True)
+            slow, sel2 = pp.thresholdKLD(list(rows), thr, a, merge=True)
+            assert len(sel) == len(sel2) > 20000
+            assert fast == slow
+            assert list(sel)[:50] == sel2[:50]
+        back = ScoreTable.from_frame(table.to_frame(), rip=False)
+        assert back.names == ScoreTable.from_rows(rows, rip=False).names
+        for f in ("seq_index", "start", "stop", "kld", "gc"):
+            assert np.array_equal(getattr(back, f), getattr(table, f)), f
+
+
+def test_python_max_semantics_of_the_otsu_scale():
+    from frisk_amd import postprocess as pp
+    nan = float("nan")
+    for vals in ([1.0, 3.0, 2.0], [nan, 3.0, 2.0], [1.0, nan, 5.0, nan], [2.0], [0.5, nan]):
+        a = np.asarray(vals).reshape(-1, 1)
+        want = max(a)           # what the reference evaluates (row by row)
+        got = pp._py_max(a)
+        assert np.array_equal(np.ravel(want), np.ravel(got), equal_nan=True), vals
+        assert np.array_equal(np.ravel(max(np.ravel(a))), np.ravel(pp._py_max(np.ravel(a))), equal_nan=True)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end timing of `python -m frisk_amd` on synthetic FASTA files of BASELINE.json's shapes (GPU box).
 Writes the FASTA (60-column lines, plain and .gz), runs the CLI with --exitAfter WindowKLD (stdout -> /dev/null) and
-prints one JSON line per run with the CLI's own timing split (FRISK_TIMING=1).  usage: e2e_cli.py C3|C5shard|C5 [workdir]"""
+prints one JSON line per run with the CLI's own timing split (FRISK_TIMING=1).  usage: e2e_cli.py C3|C5shard|C5 [workdir]
+E2E_FULL=1 adds the WHOLE pipeline (reference main() L1400-1851 as far as this package goes): scan -> log10 / Otsu threshold ->
+2-state HMM segmentation -> merged anomaly features -> RIP features, three GFF3 files
+(--RIP --hmmKLD --hmmOutfile ... --threshTypeKLD otsu --gffOutfile ...), cold and from the caches."""
 import gzip
 import json
 import os
@@ -54,6 +57,30 @@ if shape != "C5" and not os.path.exists(gz):
                 break
             dst.write(b)
     print(json.dumps({"gz": gz, "bytes": os.path.getsize(gz), "gzip_s": round(time.time() - t0, 2)}), flush=True)
+
+def gff_lines(path):
+    return sum(1 for ln in open(path) if not ln.startswith("#")) if os.path.exists(path) else None
+
+
+if os.environ.get("E2E_FULL"):
+    for label, extra in (("full pipeline, cold caches", ["--recalc", "--recalcWin"]),
+                         ("full pipeline, sequence cache + genome pickle", ["--recalcWin"]),
+                         ("full pipeline, from the window cache", [])):
+        tmp = os.path.join(work, "F_" + os.path.basename(fa))
+        cmd = [sys.executable, "-m", "frisk_amd", "-H", fa, "-k", "8", "-w", "5000", "-i", "1000", "-t", tmp, "--RIP", "--hmmKLD",
+               "--hmmOutfile", "hmm.gff3", "--threshTypeKLD", "otsu", "--gffOutfile", "anomalies.gff3"] + extra
+        env = dict(os.environ, FRISK_TIMING="1", PYTHONPATH=ROOT)
+        t0 = time.time()
+        out = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+        wall = time.time() - t0
+        split = None
+        for line in out.stderr.splitlines():
+            if line.startswith('{"frisk_timing"'):
+                split = json.loads(line)
+        print(json.dumps({"run": os.path.basename(fa), "label": label, "rc": out.returncode, "wall_s": round(wall, 2),
+                          "in_process_s": split and round(split["total_s"], 3),
+                          "features": {f: gff_lines(os.path.join(tmp, f)) for f in ("hmm.gff3", "anomalies.gff3", "RIP_annotation.gff3")},
+                          "split": split, "err": out.stderr[-400:] if out.returncode else None}), flush=True)
 
 for path in [fa] + ([gz] if os.path.exists(gz) else []):
     # second run: the packed sequence cache (<fasta>.frisk2bit) and the genome pickle of the first are there; the windows are
