@@ -444,7 +444,8 @@ def main(argv=None):
             strong = strong_block(eng, dist, torch, rank, world, red_dev, fence, few)
         if world == 1 and opts.shard_scale == 1.0:
             shard, slens = shard_block(eng, rank, lambda: step, fence, few)
-            for label, kw in (("unmasked assembly with simple repeats", synth.REPEATS_UNMASKED),
+            for label, kw in (("unmasked assembly with simple repeats of period 1, 2, 4", synth.REPEATS_UNMASKED),
+                              ("unmasked assembly with simple repeats of period 1-6 and 3 % satellite arrays", synth.REPEATS_MIXED),
                               ("soft-masked assembly with simple repeats", synth.REPEATS_SOFT)):
                 realistic.append(shape_block(eng, slens, dict(kw, seed=0xC5 + rank), step, fence, few, label))
         eng.synth(lens, **shard_kw)         # the headline batch again (inclusive block, CPU baselines)

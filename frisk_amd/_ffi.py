@@ -46,6 +46,8 @@ SYMBOLS = [
     ("frisk_seq_name", C.c_char_p, [_P, C.c_int32]),
     ("frisk_seq_len", C.c_int64, [_P, C.c_int32]),
     ("frisk_seq_synth", C.c_int, [_P, _I64P, C.c_int32, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double]),
+    ("frisk_seq_synth2", C.c_int, [_P, _I64P, C.c_int32, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_double]),
     ("frisk_seq_read", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("frisk_profile_reset", C.c_int, [_P]),
     ("frisk_profile_add", C.c_int, [_P, C.c_int, C.c_int64, C.c_int64]),

@@ -188,9 +188,9 @@ inline bool read_index(const char* path, const MappedFile& f, std::vector<FaiEnt
                 const int64_t ln = k == 0 ? 0 : (full - 1) * k / (samples - 1 > 0 ? samples - 1 : 1);
                 const char* le = f.base + r.offset + ln * r.linewidth + r.linebases;      // behind the line's last base
                 const bool ok_term = term == 1 ? le[0] == '\n' : (le[0] == '\r' && le[1] == '\n');
-                if (!ok_term || is_space((unsigned char)le[-1]) || is_space((unsigned char)le[-r.linebases])) {
-                    why = "record " + r.name + ": a line does not end where the index says"; return false;
-                }
+                bool blank = false;                                  // (the sampled lines are read in full: a blank anywhere in them)
+                for (int64_t q = 1; q <= r.linebases && !blank; ++q) blank = is_space((unsigned char)le[-q]);
+                if (!ok_term || blank) { why = "record " + r.name + ": a line does not hold bases and end where the index says"; return false; }
             }
         }
         prev_end = last;

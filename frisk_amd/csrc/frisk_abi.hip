@@ -104,6 +104,11 @@ struct frisk_ctx {
         std::vector<hipEvent_t> piece_ev;
         bool streaming = false;
         DevBuf<int64_t> d_runs;                     // the run lists of the two masks and of the PADs, as uploaded
+        // frisk_fasta_load packs on the host and keeps the 0.25 B/base form until the next load: frisk_seq_export_2bit (the CLI's
+        // sequence cache) hands it out without touching the device
+        std::vector<uint32_t, frisk_fasta::NoInitAlloc<uint32_t>> h_codes;
+        frisk_pack2::Runs h_runs;
+        bool have_host2 = false;
         int64_t* h_pads = nullptr;                  // page-locked: the PAD runs on their way to the device
         size_t h_pads_cap = 0;
         void release() {
@@ -205,6 +210,11 @@ int layout_batch(frisk_ctx* c, frisk_ctx::Batch& B, const int64_t* lens, int32_t
     B.tiled = false;
     B.tiles.clear(); B.g_name.clear(); B.g_len.clear();
     B.streaming = false;        // (piece_end is kept: frisk_seq_stage_2bit looks at the slot's previous upload)
+    if (B.have_host2) {
+        B.have_host2 = false;
+        decltype(B.h_codes)().swap(B.h_codes);
+        B.h_runs = frisk_pack2::Runs();
+    }
     return FRISK_OK;
 }
 int layout_batch(frisk_ctx* c, const int64_t* lens, int32_t n_seq) { return layout_batch(c, c->b(), lens, n_seq); }
@@ -626,6 +636,9 @@ int frisk_seq_load(frisk_ctx* c, const uint8_t* const* seqs, const int64_t* lens
     return run_pack(c);
 }
 
+static int upload_2bit(frisk_ctx* c, frisk_ctx::Batch& B, const uint32_t* codes, const int64_t* inv_runs, int64_t n_inv,
+                       const int64_t* low_runs, int64_t n_low, int64_t piece_bases, hipStream_t st);
+
 int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t* total_len_out) {
     if (!c || !path) return FRISK_E_ARG;
     frisk_fasta::Records rec;
@@ -640,34 +653,35 @@ int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t
     HIPC(c, hipSetDevice(c->device));
     int rc = layout_batch(c, rec.lens.data(), int32_t(rec.lens.size()));
     if (rc) return rc;
-    c->b().seq_name = rec.names;
-    rec.stage.resize(size_t(c->b().padded_len), uint8_t(FRISK_PAD_BYTE));          // tail padding up to a multiple of 32
-#ifdef FRISK_TUNE
-    const auto tta = std::chrono::steady_clock::now();
-#endif
-    HIPC(c, c->b().d_ascii.reserve(size_t(c->b().padded_len)));
-#ifdef FRISK_TUNE
-    const auto ttb = std::chrono::steady_clock::now();
-#endif
-    rc = h2d(c, c->b().d_ascii.p, rec.stage.data(), rec.stage.size(), c->stream);
-    if (rc) return rc;
-    HIPC(c, hipStreamSynchronize(c->stream));
+    frisk_ctx::Batch& B = c->b();
+    B.seq_name = rec.names;
+    // Packed on the HOST, by the reader's threads, into the 0.25 B/base form (seq_pack2.h): 2-bit codes + run lists of the two
+    // masks.  PCIe then carries a quarter of the bytes (3.3 GB of ASCII -> 0.82 GB for a GRCh38-sized assembly), and the host
+    // copy stays until the next load: the CLI's sequence cache is written from it without touching the device.
+    const unsigned hw = std::thread::hardware_concurrency();
+    B.h_codes.resize(size_t(B.padded_len / 32) * 2);
+    frisk_pack2::pack_stage(rec.stage.data(), rec.lens.data(), int32_t(rec.lens.size()), B.h_codes.data(), B.h_runs,
+                            int(std::min(32u, hw ? hw : 1u)));
+    B.have_host2 = true;
 #ifdef FRISK_TUNE
     const auto tt2 = std::chrono::steady_clock::now();
-    if (std::getenv("FRISK_LOAD_SPLIT"))
-        std::fprintf(stderr, "[load] layout + resize %.1f ms, device alloc %.1f ms, copy %.1f ms\n",
-                     std::chrono::duration<double, std::milli>(tta - tt1).count(), std::chrono::duration<double, std::milli>(ttb - tta).count(),
-                     std::chrono::duration<double, std::milli>(tt2 - ttb).count());
 #endif
-    rc = alloc_packed(c);
+    HIPC(c, hipEventRecord(c->ev0, c->stream));
+    rc = upload_2bit(c, B, B.h_codes.data(), B.h_runs.inv.data(), int64_t(B.h_runs.inv.size() / 2), B.h_runs.low.data(),
+                     int64_t(B.h_runs.low.size() / 2), 0, c->stream);
     if (rc) return rc;
-    rc = run_pack(c);
-    if (rc) return rc;
+    HIPC(c, hipEventRecord(c->ev1, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPC(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->ms[2] = ms;                              // (upload + mask expansion: there is no device-side packing on this path)
+    B.have_seq = true;
+    c->plan_w = -1;
 #ifdef FRISK_TUNE
     {
         const auto tt3 = std::chrono::steady_clock::now();
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        if (std::getenv("FRISK_LOAD_SPLIT")) std::fprintf(stderr, "[load] parse %.1f ms, alloc + H2D %.1f ms, pack %.1f ms\n", ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3));
+        auto msf = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        if (std::getenv("FRISK_LOAD_SPLIT")) std::fprintf(stderr, "[load] parse %.1f ms, host pack %.1f ms, upload %.1f ms\n", msf(tt0, tt1), msf(tt1, tt2), msf(tt2, tt3));
     }
 #endif
     int64_t total = 0;
@@ -961,32 +975,25 @@ static int enqueue_mask(frisk_ctx* c, frisk_ctx::Batch& B, uint32_t* d_bits, con
     return FRISK_OK;
 }
 
-int frisk_seq_stage_2bit(frisk_ctx* c, const uint32_t* codes, const int64_t* inv_runs, int64_t n_inv, const int64_t* low_runs,
-                         int64_t n_low, const int64_t* lens, int32_t n_seq, int64_t piece_bases) {
-    if (!c) return FRISK_E_ARG;
-    if (!codes || (n_seq > 0 && !lens) || (n_inv != 0 && !inv_runs) || (n_low != 0 && !low_runs))
-        return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: null array");
-    if (piece_bases < 0) return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: piece_bases < 0");
-    HIPC(c, hipSetDevice(c->device));
-    frisk_ctx::Batch& B = c->bat[c->cur ^ 1];
-    c->staged = false;
-    if (c->slot_ev_set) HIPC(c, hipStreamWaitEvent(c->copy_stream, c->slot_free_ev, 0));      // (as frisk_seq_stage)
-    int rc = layout_batch(c, B, lens, n_seq);
-    if (rc) return rc;
+// the 0.25 B/base form of batch B (laid out by the caller) onto the device, on stream `st`: masks from the run lists, the codes
+// in pieces with an event behind each
+static int upload_2bit(frisk_ctx* c, frisk_ctx::Batch& B, const uint32_t* codes, const int64_t* inv_runs, int64_t n_inv,
+                       const int64_t* low_runs, int64_t n_low, int64_t piece_bases, hipStream_t st) {
     const int64_t P = B.padded_len;
+    const int32_t n_seq = B.n_seq;
     for (const auto& L : {std::make_pair(inv_runs, n_inv), std::make_pair(low_runs, n_low)})
         for (int64_t r = 0; r < L.second; ++r)
             if (L.first[2 * r] < 0 || L.first[2 * r] > L.first[2 * r + 1] || L.first[2 * r + 1] > P)
                 return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: a run outside the batch");
-    rc = alloc_packed(c, B, c->copy_stream);
+    int rc = alloc_packed(c, B, st);
     if (rc) return rc;
     // PAD runs: the position behind every scaffold, and the batch's tail (inv AND low, frisk_device.h); adjacent ones merged
     // (the page-locked buffer they travel from may still feed the copy of this slot's previous upload: wait for that one)
     if (!B.piece_end.empty() && !B.piece_ev.empty()) HIPC(c, hipEventSynchronize(B.piece_ev[std::min(B.piece_end.size(), B.piece_ev.size()) - 1]));
     std::vector<int64_t> pads;
-    for (int32_t s = 0; s < n_seq; ++s) frisk_pack2::push_run(pads, B.seq_off[size_t(s)] + lens[s], B.seq_off[size_t(s)] + lens[s] + 1);
+    for (int32_t s = 0; s < n_seq; ++s) frisk_pack2::push_run(pads, B.seq_off[size_t(s)] + B.seq_len[size_t(s)], B.seq_off[size_t(s)] + B.seq_len[size_t(s)] + 1);
     {
-        const int64_t tail = n_seq > 0 ? B.seq_off[size_t(n_seq) - 1] + lens[n_seq - 1] + 1 : 0;
+        const int64_t tail = n_seq > 0 ? B.seq_off[size_t(n_seq) - 1] + B.seq_len[size_t(n_seq) - 1] + 1 : 0;
         if (tail < P) frisk_pack2::push_run(pads, tail, P);
     }
     const int64_t n_pads = int64_t(pads.size() / 2);
@@ -1002,10 +1009,10 @@ int frisk_seq_stage_2bit(frisk_ctx* c, const uint32_t* codes, const int64_t* inv
         B.h_pads_cap = pads.size() + pads.size() / 4 + 16;
     }
     std::memcpy(B.h_pads, pads.data(), pads.size() * sizeof(int64_t));
-    HIPC(c, hipMemcpyAsync(d_pads, B.h_pads, pads.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->copy_stream));
-    rc = enqueue_mask(c, B, B.d_inv.p, inv_runs, n_inv, d_inv_runs, d_pads, n_pads, c->copy_stream);
+    HIPC(c, hipMemcpyAsync(d_pads, B.h_pads, pads.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    rc = enqueue_mask(c, B, B.d_inv.p, inv_runs, n_inv, d_inv_runs, d_pads, n_pads, st);
     if (rc) return rc;
-    rc = enqueue_mask(c, B, B.d_low.p, low_runs, n_low, d_low_runs, d_pads, n_pads, c->copy_stream);
+    rc = enqueue_mask(c, B, B.d_low.p, low_runs, n_low, d_low_runs, d_pads, n_pads, st);
     if (rc) return rc;
     // the codes, piece by piece: an event behind each, so that phase A can follow the copies (frisk_profile_add)
     const int64_t w32 = P / 32;
@@ -1016,7 +1023,7 @@ int frisk_seq_stage_2bit(frisk_ctx* c, const uint32_t* codes, const int64_t* inv
     B.piece_end.clear();
     for (int64_t a = 0; a < w32; a += piece_words) {
         const int64_t b = std::min(w32, a + piece_words);
-        rc = h2d(c, B.d_codes.p + 2 * a, codes + 2 * a, size_t(b - a) * 8, c->copy_stream);
+        rc = h2d(c, B.d_codes.p + 2 * a, codes + 2 * a, size_t(b - a) * 8, st);
         if (rc) return rc;
         const size_t i = B.piece_end.size();
         if (B.piece_ev.size() <= i) {
@@ -1024,9 +1031,26 @@ int frisk_seq_stage_2bit(frisk_ctx* c, const uint32_t* codes, const int64_t* inv
             HIPC(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             B.piece_ev.push_back(ev);
         }
-        HIPC(c, hipEventRecord(B.piece_ev[i], c->copy_stream));
+        HIPC(c, hipEventRecord(B.piece_ev[i], st));
         B.piece_end.push_back(b);
     }
+    return FRISK_OK;
+}
+
+int frisk_seq_stage_2bit(frisk_ctx* c, const uint32_t* codes, const int64_t* inv_runs, int64_t n_inv, const int64_t* low_runs,
+                         int64_t n_low, const int64_t* lens, int32_t n_seq, int64_t piece_bases) {
+    if (!c) return FRISK_E_ARG;
+    if (!codes || (n_seq > 0 && !lens) || (n_inv != 0 && !inv_runs) || (n_low != 0 && !low_runs))
+        return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: null array");
+    if (piece_bases < 0) return fail(c, FRISK_E_ARG, "frisk_seq_stage_2bit: piece_bases < 0");
+    HIPC(c, hipSetDevice(c->device));
+    frisk_ctx::Batch& B = c->bat[c->cur ^ 1];
+    c->staged = false;
+    if (c->slot_ev_set) HIPC(c, hipStreamWaitEvent(c->copy_stream, c->slot_free_ev, 0));      // (as frisk_seq_stage)
+    int rc = layout_batch(c, B, lens, n_seq);
+    if (rc) return rc;
+    rc = upload_2bit(c, B, codes, inv_runs, n_inv, low_runs, n_low, piece_bases, c->copy_stream);
+    if (rc) return rc;
     HIPC(c, hipEventRecord(c->staged_ev, c->copy_stream));
     B.streaming = true;
     c->staged = true;
@@ -1052,6 +1076,27 @@ int frisk_seq_commit(frisk_ctx* c) {
 int frisk_seq_export_2bit(frisk_ctx* c, uint32_t* codes, int64_t** inv_runs, int64_t* n_inv, int64_t** low_runs, int64_t* n_low) {
     if (!c || !codes || !inv_runs || !n_inv || !low_runs || !n_low) return FRISK_E_ARG;
     if (!c->b().have_seq) return fail(c, FRISK_E_STATE, "no resident sequence batch");
+    auto give = [](const std::vector<int64_t>& v, int64_t** out, int64_t* n) -> bool {
+        *n = int64_t(v.size() / 2);
+        *out = static_cast<int64_t*>(std::malloc(std::max<size_t>(v.size(), 2) * sizeof(int64_t)));
+        if (!*out) return false;
+        if (!v.empty()) std::memcpy(*out, v.data(), v.size() * sizeof(int64_t));
+        return true;
+    };
+    if (c->b().have_host2) {            // packed on the host by frisk_fasta_load: the device is not involved
+        const frisk_ctx::Batch& HB = c->b();
+        const size_t nbytes = HB.h_codes.size() * 4;
+        const int T = int(std::max<size_t>(1, std::min<size_t>(8, nbytes >> 26)));
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) {
+            const size_t a = nbytes / 64 * size_t(t) / size_t(T) * 64, b = t + 1 == T ? nbytes : nbytes / 64 * size_t(t + 1) / size_t(T) * 64;
+            th.emplace_back([&, a, b] { std::memcpy(reinterpret_cast<char*>(codes) + a, reinterpret_cast<const char*>(HB.h_codes.data()) + a, b - a); });
+        }
+        for (auto& x : th) x.join();
+        if (!give(HB.h_runs.inv, inv_runs, n_inv)) return fail(c, FRISK_E_HIP, "out of host memory");
+        if (!give(HB.h_runs.low, low_runs, n_low)) { std::free(*inv_runs); *inv_runs = nullptr; return fail(c, FRISK_E_HIP, "out of host memory"); }
+        return FRISK_OK;
+    }
     HIPC(c, hipSetDevice(c->device));
     int rc = settle_stream(c);
     if (rc) return rc;
@@ -1066,13 +1111,6 @@ int frisk_seq_export_2bit(frisk_ctx* c, uint32_t* codes, int64_t** inv_runs, int
     std::thread t([&] { frisk_pack2::bitmap_runs(inv.data(), B.seq_len.data(), B.n_seq, ri); });
     frisk_pack2::bitmap_runs(low.data(), B.seq_len.data(), B.n_seq, rl);
     t.join();
-    auto give = [](const std::vector<int64_t>& v, int64_t** out, int64_t* n) -> bool {
-        *n = int64_t(v.size() / 2);
-        *out = static_cast<int64_t*>(std::malloc(std::max<size_t>(v.size(), 2) * sizeof(int64_t)));
-        if (!*out) return false;
-        if (!v.empty()) std::memcpy(*out, v.data(), v.size() * sizeof(int64_t));
-        return true;
-    };
     if (!give(ri, inv_runs, n_inv)) return fail(c, FRISK_E_HIP, "out of host memory");
     if (!give(rl, low_runs, n_low)) { std::free(*inv_runs); *inv_runs = nullptr; return fail(c, FRISK_E_HIP, "out of host memory"); }
     return FRISK_OK;
@@ -1100,6 +1138,11 @@ int frisk_seq_set_names(frisk_ctx* c, const char* const* names, int32_t n_seq) {
 
 int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t seed, double island_frac,
                     double n_frac, double lower_frac, double repeats_per_kb) {
+    return frisk_seq_synth2(c, lens, n_seq, seed, island_frac, n_frac, lower_frac, repeats_per_kb, 0.0, 0.0);
+}
+
+int frisk_seq_synth2(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t seed, double island_frac,
+                     double n_frac, double lower_frac, double repeats_per_kb, double period_mix, double sat_frac) {
     if (!c) return FRISK_E_ARG;
     if (n_seq > 0 && !lens) return fail(c, FRISK_E_ARG, "null length table");
     HIPC(c, hipSetDevice(c->device));
@@ -1111,13 +1154,15 @@ int frisk_seq_synth(frisk_ctx* c, const int64_t* lens, int32_t n_seq, uint64_t s
     synth_make_tables(seed, tabs);
     const uint32_t thr_island = synth_frac_to_u32(island_frac), thr_nbig = synth_frac_to_u32(n_frac * 0.8),
                    thr_nsmall = synth_frac_to_u32(n_frac * 0.2), thr_low = synth_frac_to_u32(lower_frac),
-                   thr_rep = synth_frac_to_u32(repeats_per_kb * (SYNTH_REP / 1000.0));
+                   thr_rep = synth_frac_to_u32(repeats_per_kb * (SYNTH_REP / 1000.0)), thr_mix = synth_frac_to_u32(period_mix),
+                   thr_sat = synth_frac_to_u32(sat_frac * (2.0 * SYNTH_SAT_GROUP / (SYNTH_SAT_GROUP + 1.0))),
+                   thr_div = synth_frac_to_u32(SYNTH_SAT_DIV);
     for (int32_t s = 0; s < n_seq; ++s) {
         if (lens[s] <= 0) continue;
         const int64_t nblk = (lens[s] + SYNTH_BLOCK - 1) / SYNTH_BLOCK;
         synth_kernel<<<grid_for(nblk, 64, 1 << 20), 64, 0, c->stream>>>(c->b().d_ascii.p + c->b().seq_off[size_t(s)], lens[s],
                                                                        seed, uint32_t(s), tabs, thr_island, thr_nbig,
-                                                                       thr_nsmall, thr_low, thr_rep);
+                                                                       thr_nsmall, thr_low, thr_rep, thr_mix, thr_sat, thr_div);
         HIPC(c, hipGetLastError());
     }
     rc = alloc_packed(c);

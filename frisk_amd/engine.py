@@ -278,11 +278,12 @@ class Engine:
         names = [self._lib.frisk_seq_name(self._ctx, i).decode("ascii", "replace") for i in range(self.n_seq)]
         return names, (int(c0.value), int(c1.value))
 
-    def synth(self, lens, seed, island_frac=0.02, n_frac=0.0, lower_frac=0.0, repeats_per_kb=0.0):
+    def synth(self, lens, seed, island_frac=0.02, n_frac=0.0, lower_frac=0.0, repeats_per_kb=0.0, period_mix=0.0, sat_frac=0.0):
         lens = [int(x) for x in lens]
         arr = (C.c_int64 * max(len(lens), 1))(*lens)
-        self._check(self._lib.frisk_seq_synth(self._ctx, arr, len(lens), C.c_uint64(seed), float(island_frac),
-                                              float(n_frac), float(lower_frac), float(repeats_per_kb)))
+        self._check(self._lib.frisk_seq_synth2(self._ctx, arr, len(lens), C.c_uint64(seed), float(island_frac),
+                                               float(n_frac), float(lower_frac), float(repeats_per_kb), float(period_mix),
+                                               float(sat_frac)))
         self.n_seq = len(lens)
         self.seq_lens = lens
 

@@ -138,7 +138,8 @@ def merge_intervals(records, dist=0, ops=("max",), cols=(3,)):
         summary = []
         for op, col in zip(ops, cols):
             vals = np.array([float(m[col]) for m in members], dtype=float)
-            v = {"max": vals.max, "min": vals.min, "mean": vals.mean}[op]()
+            # (mean: a sequential sum over the members / their number, as bedtools accumulates it - and as merge_columns does)
+            v = {"max": vals.max, "min": vals.min, "mean": lambda: np.add.reduceat(vals, [0])[0] / len(vals)}[op]()
             summary.append(_prec5(v))
         merged.append((chrom, start, end) + tuple(summary))
     return merged
@@ -148,6 +149,19 @@ def _name_ranks(names):
     """rank of every scaffold NAME in Python's string order (the sort key of L655 / L710), equal names sharing a rank."""
     order = {nm: r for r, nm in enumerate(sorted(set(names)))}
     return np.asarray([order[nm] for nm in names], dtype=np.int64)
+
+
+def _sort_rows(rank, start, stop, idx):
+    """Rows idx ordered by (name rank, start, stop).  A table comes out of the scan scaffold by scaffold with ascending windows,
+    so a stable sort on the rank alone usually does it (checked; jumpback rows can step back by one base: then the full sort)."""
+    o = np.argsort(rank, kind="stable")
+    i2, r2 = idx[o], rank[o]
+    st, sp = start[i2], stop[i2]
+    same = r2[1:] == r2[:-1]
+    if np.any(same & ((st[1:] < st[:-1]) | ((st[1:] == st[:-1]) & (sp[1:] < sp[:-1])))):
+        o = np.lexsort((stop[idx], start[idx], rank))
+        i2, r2 = idx[o], rank[o]
+    return i2, r2
 
 
 def merge_columns(names, name_rank, start, stop, values, dist=0, ops=("max",), cols=(0,)):
@@ -174,12 +188,10 @@ def merge_columns(names, name_rank, start, stop, values, dist=0, ops=("max",), c
             r = np.minimum.reduceat(v, a)
         else:
             r = np.add.reduceat(v, a) / cnt
-            big_groups = np.nonzero(cnt >= 8)[0]          # numpy's mean sums pairwise from 8 elements on: take its value there
-            for g in big_groups.tolist():
-                r[g] = v[a[g]:a[g] + cnt[g]].mean()
         summ.append(["%.5g" % x for x in r.tolist()])
-    return [(names[i], s0, e0) + tuple(c[k] for c in summ)
-            for k, (i, s0, e0) in enumerate(zip(a.tolist(), start[a].tolist(), ends.tolist()))]
+    first = names[a].tolist() if isinstance(names, np.ndarray) else [names[i] for i in a.tolist()]
+    return [(nm, s0, e0) + tuple(c[k] for c in summ)
+            for k, (nm, s0, e0) in enumerate(zip(first, start[a].tolist(), ends.tolist()))]
 
 
 def thresholdKLD(table, threshold, args, merge=True):
@@ -194,9 +206,8 @@ def thresholdKLD(table, threshold, args, merge=True):
         idx = np.nonzero(pick & ~np.isnan(kld))[0]
         if merge and idx.size > 20000 and getattr(args, "mergeDist", 0) >= 0:      # many windows selected (3 M rows, an Otsu cut): sort and merge on the columns
             rank = _name_ranks(table.names)[table.seq_index[idx]]
-            order = np.lexsort((table.stop[idx], table.start[idx], rank))
-            idx, rank = idx[order], rank[order]
-            nm = [table.names[i] for i in table.seq_index[idx].tolist()]
+            idx, rank = _sort_rows(rank, table.start, table.stop, idx)
+            nm = np.asarray(table.names, dtype=object)[table.seq_index[idx]]
             feats = merge_columns(nm, rank, table.start[idx], table.stop[idx], [kld[idx]], dist=getattr(args, "mergeDist", 0),
                                   ops=("max", "min", "mean"), cols=(0, 0, 0))
             return feats, _LazyRows(table, idx)
@@ -252,14 +263,38 @@ def thresholdRIP(table, args):
     """RIP features (L692-720): windows with PI >= minPI, SI <= maxSI, CRI >= minCRI are merged
     (`-d 0 -c 4,5,6,7,7 -o max,min,max,min,max`) and kept if they overlap at least one window with
     CRI >= peakCRI (`window -w 0 -u`).  table rows: (name, start, stop, KLD, GC, PI, SI, CRI)."""
-    if hasattr(table, "kld"):           # a ScoreTable: filter on the columns first (RIP features are rare)
+    if hasattr(table, "kld"):           # a ScoreTable: everything on the columns (3 M rows: no tuple per window)
         with np.errstate(invalid="ignore"):
             ok_m = ~(np.isnan(table.kld) | np.isnan(table.pi) | np.isnan(table.si) | np.isnan(table.cri))
-            basic_m = ok_m & (table.pi >= args.minPI) & (table.si <= args.maxSI) & (table.cri >= args.minCRI)
-            peak_m = ok_m & (table.cri >= args.peakCRI)
-        key = lambda r: (r[0], r[1], r[2])      # noqa: E731
-        basic = sorted(table.rows(np.nonzero(basic_m)[0]), key=key)
-        peaks = sorted(table.rows(np.nonzero(peak_m)[0]), key=key)
+            basic_i = np.nonzero(ok_m & (table.pi >= args.minPI) & (table.si <= args.maxSI) & (table.cri >= args.minCRI))[0]
+            peak_i = np.nonzero(ok_m & (table.cri >= args.peakCRI))[0]
+        if basic_i.size == 0 or peak_i.size == 0:
+            return None
+        ranks = _name_ranks(table.names)
+        names_o = np.asarray(table.names, dtype=object)
+
+        def ordered(idx):
+            return _sort_rows(ranks[table.seq_index[idx]], table.start, table.stop, idx)
+        basic_i, brank = ordered(basic_i)
+        peak_i, prank = ordered(peak_i)
+        kld = np.where(table.kld_is_int0[basic_i] != 0, 0.0, table.kld[basic_i])
+        merged = merge_columns(names_o[table.seq_index[basic_i]], brank, table.start[basic_i], table.stop[basic_i],
+                               [kld, table.pi[basic_i], table.si[basic_i], table.cri[basic_i]], dist=0,
+                               ops=("max", "min", "max", "min", "max"), cols=(0, 1, 2, 3, 3))
+        # bedtools window -w 0 -u: keep a feature that overlaps a peak window (half-open BED arithmetic).  Peaks sorted by
+        # (scaffold, start) with the running maximum of their ends inside the scaffold: a feature overlaps one iff, among the
+        # scaffold's peaks that start before its end, some end lies behind its start
+        big = int(max(int(table.stop.max()), int(table.start.max()), 0)) + 2
+        pkey = prank * big + table.start[peak_i]
+        pend = np.maximum.accumulate(prank * big + table.stop[peak_i])
+        rank_of = dict(zip(table.names, ranks.tolist()))
+        frank = np.asarray([rank_of[f[0]] for f in merged], dtype=np.int64)
+        fstart = np.asarray([f[1] for f in merged], dtype=np.int64)
+        fend = np.asarray([f[2] for f in merged], dtype=np.int64)
+        k = np.searchsorted(pkey, frank * big + fend, side="left")
+        hit = (k > 0) & (pend[np.maximum(k, 1) - 1] > frank * big + fstart)
+        keep = [f for f, h in zip(merged, hit.tolist()) if h]
+        return keep or None
     else:
         ok = [r for r in table if not any(isinstance(v, float) and v != v for v in (r[3], r[5], r[6], r[7]))]
         ok.sort(key=lambda r: (r[0], r[1], r[2]))

@@ -15,6 +15,16 @@ bytes: every property of a base is a pure function of (seed, scaffold index, pos
                 bench: a primate assembly as UCSC distributes it (soft-masked: the reference's 30 % filter - which counts
                 lowercase as unresolved, L106-118 - then drops most windows) and as an unmasked download (every window
                 scored, and poly-A tails / microsatellites overflow 4-bit counters in almost half of them)
+  * period_mix: a share period_mix of those repeats is instead of period 3, 5 or 6 - (CAG)n, (AAT)n, (AAAAT)n, (TTAGGG)n, in
+                equal parts - with a longer tail (12..31 bases, one in four up to 210, cut at the unit's end).  The classes'
+                shares in REPEATS_MIXED (period 1: 47 %, 2: 19 %, 4: 9 %, 3: 12.5 %, 5 and 6: 6 % each) are a rough reading of
+                the microsatellite census of the human genome (mono- > di- > tetra- / penta- > tri- > hexanucleotide repeats;
+                no network here to pin a table: the proportions are this file's own, stated so that they can be argued with)
+  * satellites: a share sat_frac of the bases lies in tandem arrays of a 171-base monomer (its own per array) with 3 %
+                divergence between copies: the first 1..8 units of 131 072 bases in a group of 8 (0.13..1.05 Mb; neighbouring
+                groups merge) - alpha-satellite-like: every 8-mer of the monomer occurs ~23 times in a 5 kb window, none of
+                them of a short period.  REPEATS_MIXED takes 3 % (the alpha-satellite share of a telomere-to-telomere human
+                assembly)
 """
 import numpy as np
 
@@ -27,6 +37,13 @@ REP = 512
 # the bench's realistic shapes: one simple repeat per ~3 kb (Alu poly-A tails + microsatellites), 7 % N
 REPEATS_SOFT = dict(island_frac=0.02, n_frac=0.07, lower_frac=0.45, repeats_per_kb=0.35)
 REPEATS_UNMASKED = dict(island_frac=0.02, n_frac=0.07, lower_frac=0.0, repeats_per_kb=0.35)
+# ... and the shape that is NOT built around the scan kernel's side table (periods <= 4): a quarter of the simple repeats of
+# period 3 / 5 / 6, and 3 % of the bases in satellite arrays
+REPEATS_MIXED = dict(island_frac=0.02, n_frac=0.07, lower_frac=0.0, repeats_per_kb=0.35, period_mix=0.25, sat_frac=0.03)
+SAT_UNIT = 131072
+SAT_GROUP = 8
+SAT_MONOMER = 171
+SAT_DIV = 0.03
 GOLDEN = np.uint64(0x9E3779B97F4A7C15)
 _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
@@ -70,7 +87,31 @@ def make_tables(seed):
     return bg, isl
 
 
-def _repeats(length, seed, scaf_index, repeats_per_kb):
+def _satellite(length, seed, scaf_index, sat_frac):
+    """(in_satellite mask, base digit) per position - the `sat` branch of synth_kernel."""
+    thr = frac_to_u32(sat_frac * (2.0 * SAT_GROUP / (SAT_GROUP + 1.0)))
+    if thr == 0:
+        return np.zeros(length, bool), np.zeros(length, np.int64)
+    pos = np.arange(length, dtype=np.int64)
+    unit = pos // SAT_UNIT
+    group = unit // SAT_GROUP
+    ng = int(group[-1]) + 1
+    g = np.arange(ng, dtype=np.uint64)
+    on_g = _unit_hash(seed, scaf_index, g, 8) < np.uint32(thr)
+    take = 1 + (_unit_hash(seed, scaf_index, g, 9).astype(np.int64) >> 8) % SAT_GROUP
+    sat = on_g[group] & ((unit % SAT_GROUP) < take[group])
+    base = np.zeros(length, np.int64)
+    idx = np.nonzero(sat)[0]
+    if idx.size:
+        j = (idx - group[idx] * (SAT_UNIT * SAT_GROUP)) % SAT_MONOMER
+        b = _unit_hash(seed, scaf_index, (group[idx] * 256 + j).astype(np.uint64), 10).astype(np.int64) >> 30
+        hd = _unit_hash(seed, scaf_index, idx.astype(np.uint64), 11)
+        b = np.where(hd < np.uint32(frac_to_u32(SAT_DIV)), hd.astype(np.int64) & 3, b)
+        base[idx] = b
+    return sat, base
+
+
+def _repeats(length, seed, scaf_index, repeats_per_kb, period_mix=0.0):
     """(in_repeat mask, repeat base digit) per position - synth_repeat_of / synth_repeat_base of csrc/synth_kernel.h."""
     pos = np.arange(length, dtype=np.int64)
     unit = pos // REP
@@ -86,21 +127,32 @@ def _repeats(length, seed, scaf_index, repeats_per_kb):
     kind = h & 7
     period = np.where(kind < 5, 1, np.where(kind < 7, 2, 4))
     motif = np.where(kind < 3, 0x0, np.where(kind < 5, 0x1, np.where(kind == 5, 0xC, np.where(kind == 6, 0x6, 0x01))))
+    thr_mix = frac_to_u32(period_mix)
+    if thr_mix:
+        mixed = _unit_hash(seed, scaf_index, u, 7) < np.uint32(thr_mix)
+        which = (h >> 1) & 3
+        period = np.where(mixed, np.where(which < 2, 3, np.where(which == 2, 5, 6)), period)
+        motif = np.where(mixed, np.where(which == 0, 0x32, np.where(which == 1, 0x01, np.where(which == 2, 0x001, 0x52A))), motif)
+        ln2 = 12 + (h >> 3) % 20 + np.where(((h >> 8) & 3) == 0, (h >> 12) % 180, 0)
+        room = (np.arange(nunit, dtype=np.int64) + 1) * REP - start
+        ln = np.where(mixed, np.minimum(ln2, room), ln)
     inside = on[unit] & (pos >= start[unit]) & (pos < start[unit] + ln[unit])
     k = (pos - start[unit]) % period[unit]
     base = (motif[unit] >> (2 * (period[unit] - 1 - k))) & 3
     return inside, base
 
 
-def scaffold(length, seed, scaf_index, island_frac=0.02, n_frac=0.0, lower_frac=0.0, repeats_per_kb=0.0):
+def scaffold(length, seed, scaf_index, island_frac=0.02, n_frac=0.0, lower_frac=0.0, repeats_per_kb=0.0, period_mix=0.0, sat_frac=0.0):
     """bytes of one synthetic scaffold (vectorised over its 4096-base blocks)."""
     length = int(length)
     if length <= 0:
         return b""
     bg, isl = make_tables(seed)
     nblk = (length + BLOCK - 1) // BLOCK
-    in_rep, rep_base = _repeats(nblk * BLOCK, seed, scaf_index, repeats_per_kb)
+    in_rep, rep_base = _repeats(nblk * BLOCK, seed, scaf_index, repeats_per_kb, period_mix)
     in_rep, rep_base = in_rep.reshape(nblk, BLOCK), rep_base.reshape(nblk, BLOCK)
+    in_sat, sat_base = _satellite(nblk * BLOCK, seed, scaf_index, sat_frac)
+    in_sat, sat_base = in_sat.reshape(nblk, BLOCK), sat_base.reshape(nblk, BLOCK)
     blk = np.arange(nblk, dtype=np.uint64)
     island = _unit_hash(seed, scaf_index, blk // np.uint64(ISLAND_BLOCKS), 1) < np.uint32(frac_to_u32(island_frac))
     key = (np.uint64(scaf_index) << np.uint64(40)) ^ blk
@@ -117,13 +169,14 @@ def scaffold(length, seed, scaf_index, island_frac=0.02, n_frac=0.0, lower_frac=
             row = tab[rows, ctx]                                        # (nblk, 4)
             b = (r >= row[:, 0]).astype(np.int64) + (r >= row[:, 1]) + (r >= row[:, 2])
             b = np.where(in_rep[:, t], rep_base[:, t], b)
+            b = np.where(in_sat[:, t], sat_base[:, t], b)
             ctx = ((ctx << 2) | b) & 63
             out[:, t] = letters[b]
     seq = out.reshape(-1)[:length].copy()
     pos = np.arange(length, dtype=np.uint64)
     low = _unit_hash(seed, scaf_index, pos // np.uint64(LOWER), 4) < np.uint32(frac_to_u32(lower_frac))
     if frac_to_u32(lower_frac) != 0:            # an assembly is soft-masked - repeats included - or it is not
-        low = low | in_rep.reshape(-1)[:length]
+        low = low | in_rep.reshape(-1)[:length] | in_sat.reshape(-1)[:length]
     seq[low] |= 0x20
     nbig = _unit_hash(seed, scaf_index, pos // np.uint64(BLOCK * NBIG_BLOCKS), 2) < np.uint32(frac_to_u32(n_frac * 0.8))
     nsmall = _unit_hash(seed, scaf_index, pos // np.uint64(NSMALL), 3) < np.uint32(frac_to_u32(n_frac * 0.2))

@@ -162,6 +162,11 @@ int64_t frisk_seq_len(const frisk_ctx* ctx, int32_t seq_index);
  * frisk_amd/synth.py, which reproduces it bit-for-bit on the host). */
 int frisk_seq_synth(frisk_ctx* ctx, const int64_t* lens, int32_t n_seq, uint64_t seed,
                     double island_frac, double n_frac, double lower_frac, double repeats_per_kb);
+/* ... with repeat content no table of the scan kernel is shaped after: a share period_mix of the simple repeats is of period 3, 5
+ * or 6 ((CAG)n, (AAT)n, (AAAAT)n, (TTAGGG)n, up to 210 bases), and a share sat_frac of the bases lies in satellite arrays - tandem
+ * copies of a 171-base monomer, 3 % divergence between copies, 0.13 .. 1.05 Mb each (frisk_amd/synth.py is the specification). */
+int frisk_seq_synth2(frisk_ctx* ctx, const int64_t* lens, int32_t n_seq, uint64_t seed, double island_frac, double n_frac,
+                     double lower_frac, double repeats_per_kb, double period_mix, double sat_frac);
 
 /* Copy bases [offset, offset+n) of resident scaffold seq_index back as ASCII (canonical letters:
  * A/T/G/C, a/t/g/c, N for every non-ACGT letter) - test / bench-sampling utility. */

@@ -130,13 +130,16 @@ def test_an_index_is_only_good_for_its_file(tmp_path):
     assert "another version" in refused(idx)
     os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
     _all_equal(path, idx)
-    # a foreign (unstamped) index: accepted when it is not older than the file and every record is where it says
+    # a foreign (unstamped) index: accepted when it is NEWER than the file and every record is where it says
     body = open(idx).read().splitlines()[1:]
     foreign = tmp_path / "g.fa.fai"
     foreign.write_text("\n".join(body) + "\n")
+    os.utime(foreign, ns=(st.st_atime_ns, st.st_mtime_ns + 5_000_000_000))
     _all_equal(path, foreign)
     os.utime(foreign, ns=(st.st_atime_ns, st.st_mtime_ns - 5_000_000_000))
-    assert "older" in refused(foreign)
+    assert "not newer" in refused(foreign)
+    os.utime(foreign, ns=(st.st_atime_ns, st.st_mtime_ns))            # (same instant: a regenerated file with the same offsets)
+    assert "not newer" in refused(foreign)
     os.utime(foreign, ns=(st.st_atime_ns, st.st_mtime_ns + 5_000_000_000))
     # ... and refused when it describes another file: an offset that is no line start, a wrong name, a wrong length
     cols = [ln.split("\t") for ln in body]
@@ -152,6 +155,18 @@ def test_an_index_is_only_good_for_its_file(tmp_path):
         assert why in refused(foreign), why
     foreign.write_text("not an index\n")
     assert "malformed" in refused(foreign)
+    # a foreign index of a file with blanks INSIDE its sequence lines (samtools counts graphic characters only; the reference's
+    # reader strips whole lines): record boundaries can look right while interior lines are not where the arithmetic puts them
+    odd = tmp_path / "odd.fa"
+    odd.write_bytes(b">r\n" + b"ACGTACGTAC\n" * 3 + b"ACGT ACGTA\n" + b"ACGTACGTAC\n" * 2 + b"A\n")
+    sam = tmp_path / "odd.fa.fai"
+    sam.write_text("r\t60\t3\t10\t11\n")               # what `samtools faidx` writes for it: 60 graphic characters - and the
+                                                         # record then ENDS where the arithmetic says (the one-base last line hides the blank)
+    so = os.stat(odd)
+    os.utime(sam, ns=(so.st_atime_ns, so.st_mtime_ns + 5_000_000_000))
+    with pytest.raises(_ffi.FriskHipError) as e:
+        readFastaIndexed(str(odd), str(sam), 0, 0, 60)
+    assert e.value.code == _ffi.E_INDEX and "does not hold bases" in str(e.value)
     assert fastaIndexPaths(str(path), str(tmp_path / "tmp")) == [str(tmp_path / "tmp" / "g.fa.frisk.fai"), str(path) + ".frisk.fai",
                                                                  str(path) + ".fai"]
 

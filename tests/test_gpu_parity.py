@@ -28,9 +28,11 @@ def synth_seqs(lens, seed, **kw):
 
 @pytest.mark.parametrize("kw", [dict(island_frac=0.4, n_frac=0.25, lower_frac=0.3),
                                 dict(island_frac=0.1, n_frac=0.05, lower_frac=0.3, repeats_per_kb=1.2),      # soft-masked, with repeats
-                                dict(island_frac=0.1, n_frac=0.05, lower_frac=0.0, repeats_per_kb=1.9)])     # unmasked, with repeats
+                                dict(island_frac=0.1, n_frac=0.05, lower_frac=0.0, repeats_per_kb=1.9),      # unmasked, with repeats
+                                dict(island_frac=0.1, n_frac=0.05, lower_frac=0.0, repeats_per_kb=1.9, period_mix=0.5, sat_frac=0.3),
+                                dict(island_frac=0.1, n_frac=0.02, lower_frac=0.2, repeats_per_kb=1.0, period_mix=1.0, sat_frac=0.2)])
 def test_device_generator_equals_host_generator(kw):
-    lens = [10000, 4096, 4097, 1, 33000, 70001]
+    lens = [10000, 4096, 4097, 1, 33000, 70001] + ([1_400_000] if kw.get("sat_frac") else [])     # (satellite arrays: units of 131 072 bases)
     with make_engine(1, 4) as e:
         e.synth(lens, seed=99, **kw)
         host = synth_seqs(lens, 99, **kw)
@@ -400,7 +402,8 @@ def test_many_small_scaffolds():
             assert worst <= KLD_TOL
 
 
-@pytest.mark.parametrize("shape", ["C1", "C2", "C3", "C4", "C5", "C5/8 unmasked repeats", "C5/8 soft-masked repeats"])
+@pytest.mark.parametrize("shape", ["C1", "C2", "C3", "C4", "C5", "C5/8 unmasked repeats", "C5/8 soft-masked repeats",
+                                   "C5/8 repeats of period 1-6 + satellite arrays"])
 def test_full_size_rows_against_c_oracle(shape):
     """BASELINE configs at full size, row by row against the compiled CPU oracle (oracle/frisk_oracle_c.c, pinned to the
     reference's golden vectors by tests/test_oracle_c.py): profile bit-exact, kept set / coordinates / GC bit-exact,
@@ -426,6 +429,7 @@ def test_full_size_rows_against_c_oracle(shape):
         lens = synth.c5_shard_lens(8, 0)
         kmin, kmax, w, inc, nfrac = 1, 8, 5000, 1000, 0.07
         slices = [(0, 30000), (200_000, 230_000), (380_000, 410_000)]
+    sat_slices = 0
     with make_engine(kmin, kmax) as e:
         seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5}.get(shape, 0xC5)
         kw = dict(island_frac=0.02, n_frac=nfrac, lower_frac=0.01)
@@ -433,6 +437,8 @@ def test_full_size_rows_against_c_oracle(shape):
             kw = dict(synth.REPEATS_UNMASKED)
         elif shape == "C5/8 soft-masked repeats":
             kw = dict(synth.REPEATS_SOFT)
+        elif shape.startswith("C5/8 repeats of period"):    # the shape the side table was NOT designed around (synth.py)
+            kw = dict(synth.REPEATS_MIXED)
         if shape in ("C1", "C2", "C3"):
             # the oracle's input is generated on the HOST (frisk_amd/synth.py) and uploaded as ASCII: the GPU's pack, its
             # counters and its scores are all on the checked path, nothing the oracle sees has passed through the device
@@ -447,6 +453,16 @@ def test_full_size_rows_against_c_oracle(shape):
         res = e.scan(w, inc, rip=True)
         if S is None:                   # 249 Mb / 3.3 Gb: generated on the device, read back (the generators are tested equal)
             S = OC.Seqs([e.read_seq(q) for q in range(len(lens))])
+        if shape.startswith("C5/8 repeats of period"):
+            # ... and slices INSIDE satellite arrays of the largest scaffold (every window there wraps 4-bit counters with max-mers
+            # of no short period: the hand-over chain's case), found from the generator's own specification
+            sat, _ = synth._satellite(lens[0], seed, 0, kw["sat_frac"])
+            edges = np.nonzero(np.diff(sat.astype(np.int8)) == 1)[0]
+            assert edges.size >= 2 and abs(sat.mean() - kw["sat_frac"]) < 0.02
+            for pos in edges[:3].tolist():
+                a = max(0, pos // inc - 10)
+                slices.append((a, a + 400))
+                sat_slices += 1
         osym, ometa = OC.genome_profile(S, kmin, kmax)
         assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa)
         ig = OC.genome_ivom(osym, ometa, kmin, kmax)
@@ -468,6 +484,8 @@ def test_full_size_rows_against_c_oracle(shape):
         assert checked > (5000 if shape != "C1" else 40)
         if shape == "C5/8 unmasked repeats":        # the path real assemblies take: 4-bit counters + the side table for period-4 max-mers
             assert e.scan_stat()[0] == 4 and e.scan_side()
+        if sat_slices:
+            assert e.scan_stat()[1] > 3000      # windows handed from 4-bit to 8-bit counters (the arrays: ~3 % of 410 k)
 
 
 @pytest.mark.parametrize("want_rip", [False, True])

@@ -152,3 +152,49 @@ def test_python_max_semantics_of_the_otsu_scale():
         got = pp._py_max(a)
         assert np.array_equal(np.ravel(want), np.ravel(got), equal_nan=True), vals
         assert np.array_equal(np.ravel(max(np.ravel(a))), np.ravel(pp._py_max(np.ravel(a))), equal_nan=True)
+
+
+def test_merge_against_documented_bedtools_semantics():
+    """tests/golden/bedtools_merge_semantics.json: cases transcribed from the documented behaviour of `bedtools merge`
+    (the manual's own examples first) - data that neither restatement of this package produced.  Both the row merge and the
+    column merge must give them."""
+    import json
+    import os
+    from frisk_amd import postprocess as pp
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bedtools_merge_semantics.json")
+    doc = json.load(open(path))
+    assert len(doc["cases"]) >= 8
+    for c in doc["cases"]:
+        recs = [tuple(r) for r in c["records"]]
+        got = pp.merge_intervals(recs, dist=c["d"], ops=tuple(c["ops"]), cols=tuple(c["cols"]))
+        assert [list(g) for g in got] == c["expected"], c["name"]
+        if c["d"] >= 0:                  # (the column merge is used for non-negative distances only)
+            names = [r[0] for r in recs]
+            rank = pp._name_ranks(names)
+            start = np.array([r[1] for r in recs], dtype=np.int64)
+            stop = np.array([r[2] for r in recs], dtype=np.int64)
+            width = max(len(r) for r in recs)
+            vals = [np.array([float(r[k]) if k < len(r) else 0.0 for r in recs]) for k in range(3, width)]
+            fast = pp.merge_columns(names, rank, start, stop, vals, dist=c["d"], ops=tuple(c["ops"]), cols=tuple(k - 3 for k in c["cols"]))
+            assert [list(g) for g in fast] == c["expected"], c["name"]
+
+
+def test_rip_features_on_columns_equal_the_row_path():
+    """thresholdRIP on a ScoreTable (merge and the bedtools-window overlap test on numpy columns) == the row-by-row path."""
+    from types import SimpleNamespace
+    from frisk_amd import postprocess as pp
+    from frisk_amd.table import ScoreTable
+    rng = np.random.default_rng(12)
+    for trial in range(8):
+        rows = []
+        for nm in ["c%d" % i for i in rng.permutation(9)]:
+            for j in range(int(rng.integers(50, 900))):
+                pi, si = float(rng.normal(1.05, 0.15)), float(rng.normal(0.95, 0.15))
+                cri = float("nan") if rng.random() < 0.03 else pi - si
+                rows.append((nm, 1 + 1000 * j, 5000 + 1000 * j, float(abs(rng.normal(0.05, 0.02))), 0.5, pi, si, cri))
+        a = SimpleNamespace(minPI=1.1, maxSI=0.9, minCRI=0.1, peakCRI=float(rng.choice([0.3, 0.5, 5.0])))
+        slow = pp.thresholdRIP(list(rows), a)
+        fast = pp.thresholdRIP(ScoreTable.from_rows(rows, rip=True), a)
+        assert fast == slow
+        if slow:
+            assert "".join(pp.RIP2GFF(fast)) == "".join(pp.RIP2GFF(slow))
