@@ -142,7 +142,8 @@ struct frisk_ctx {
     DevBuf<double> d_ig, d_logtab, d_logtab64, d_logtab32, d_rctab;
     DevBuf<int64_t> d_ovf_list, d_ovf_list2;   // windows handed from 4-bit to 8-bit counters, and from there to the 16-bit form
     uint64_t ig_gen = 1, ring_gen = 0;         // the genome table's generation, and the one whose copy heads d_ig_ring
-    DevBuf<double> d_ig_ring;                  // scan8_kernel: per-workgroup ring of genome-side values by position (80 KB each at 20 positions per lane)
+    DevBuf<double> d_ig_ring;                  // scan8_kernel: per-workgroup ring of genome-side values by position (40 KB each at 20 positions per lane)
+    DevBuf<unsigned int> d_verdict;            // the adaptive width's verdict, written on the device by scan8_decide_kernel: {form, handed, would-have, scored}
     DevBuf<unsigned int> d_ovf_count;          // per row segment 32 counters: [0], [1] the lists' lengths, [8..15] the bulk launch's chunk queues, [16] the 8-bit launch's
     int64_t scan_stat[5] = {0, 0, 0, 0, 0};    // most recent scan: counter width of the bulk launch, windows handed 4->8, ->16, row segments,
                                                // 1 = the bulk launch had the side table for period-4 max-mers beside its 4-bit counters
@@ -164,6 +165,11 @@ struct frisk_ctx {
     DevBuf<int64_t> o_start, o_stop, o_meta;
     DevBuf<uint32_t> o_status, o_counts;
     DevBuf<double> o_kld, o_gc, o_pi, o_si, o_cri, o_sw, o_sg, o_ivom;
+    // a SHORT scan's row columns sit in one device block and travel to the host as ONE copy into this page-locked block (the
+    // runtime spaces small device-to-host copies ~14 us apart: seven of them were 0.1 ms behind a 0.3 ms scan)
+    DevBuf<double> o_block;
+    void* h_block = nullptr;
+    size_t h_block_cap = 0;
     double* want_ivom = nullptr;     // frisk_scan_ivom: host buffer of the per-max-mer dump requested from the next debug scan
 };
 
@@ -551,6 +557,7 @@ int frisk_create(int device, int kmin, int kmax, frisk_ctx** out) {
         HIPC(c, c->d_rctab.reserve(256));
         HIPC(c, hipMemcpyAsync(c->d_rctab.p, rc, sizeof(rc), hipMemcpyHostToDevice, c->stream));
         HIPC(c, c->d_ovf_count.reserve(64));
+        HIPC(c, c->d_verdict.reserve(8));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -562,7 +569,7 @@ void frisk_destroy(frisk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->bat[0].release(); c->bat[1].release();
-    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_logtab64.release(); c->d_logtab32.release(); c->d_rctab.release(); c->d_ig_ring.release(); c->d_ovf_list.release(); c->d_ovf_list2.release(); c->d_ovf_count.release(); c->d_big.release(); c->d_desc.release();
+    c->d_raw.release(); c->d_cnt.release(); c->d_sym.release(); c->d_ig.release(); c->d_logtab.release(); c->d_logtab64.release(); c->d_logtab32.release(); c->d_rctab.release(); c->d_ig_ring.release(); c->d_ovf_list.release(); c->d_ovf_list2.release(); c->d_ovf_count.release(); c->d_verdict.release(); c->d_big.release(); c->d_desc.release();
     c->o_seq.release(); c->o_start.release(); c->o_stop.release(); c->o_meta.release();
     c->o_status.release(); c->o_counts.release();
     c->o_ivom.release(); c->o_kld.release(); c->o_gc.release(); c->o_sw.release(); c->o_sg.release(); c->o_pi.release(); c->o_si.release(); c->o_cri.release();
@@ -578,6 +585,8 @@ void frisk_destroy(frisk_ctx* c) {
     if (c->ev_tail_kernels) (void)hipEventDestroy(c->ev_tail_kernels);
     if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
     if (c->h_meta) (void)hipHostFree(c->h_meta);
+    if (c->h_block) (void)hipHostFree(c->h_block);
+    c->o_block.release();
     if (c->evp0) (void)hipEventDestroy(c->evp0);
     if (c->evp1) (void)hipEventDestroy(c->evp1);
     c->d_meta.release();
@@ -1482,10 +1491,25 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
     if (int rs = settle_stream(c)) return rs;
     const bool debug = dbg_counts || dbg_meta;
     const size_t N = size_t(n);
-    HIPC(c, c->o_seq.reserve(N)); HIPC(c, c->o_start.reserve(N)); HIPC(c, c->o_stop.reserve(N));
-    HIPC(c, c->o_status.reserve(N)); HIPC(c, c->o_kld.reserve(N)); HIPC(c, c->o_gc.reserve(N));
+    // short scans: the row columns as consecutive pieces of one block - [start | stop | kld | gc | pi si cri | seq_index | status] - so
+    // that one copy brings them to the host
+    const bool packed_rows = n < (int64_t(1) << 17);
+    const size_t Np = (N + 1) / 2 * 2;                          // (the two 4-byte columns end on a multiple of 8 bytes)
+    const size_t blk_words = packed_rows ? (4 + (rip ? 3 : 0)) * Np + Np : 0;      // in doubles
+    if (packed_rows) {
+        HIPC(c, c->o_block.reserve(blk_words));
+        if (c->h_block_cap < blk_words * 8) {
+            if (c->h_block) HIPC(c, hipHostFree(c->h_block));
+            c->h_block = nullptr; c->h_block_cap = 0;
+            HIPC(c, hipHostMalloc(&c->h_block, blk_words * 8 + blk_words, hipHostMallocDefault));
+            c->h_block_cap = blk_words * 8 + blk_words;
+        }
+    } else {
+        HIPC(c, c->o_seq.reserve(N)); HIPC(c, c->o_start.reserve(N)); HIPC(c, c->o_stop.reserve(N));
+        HIPC(c, c->o_status.reserve(N)); HIPC(c, c->o_kld.reserve(N)); HIPC(c, c->o_gc.reserve(N));
+        if (rip) { HIPC(c, c->o_pi.reserve(N)); HIPC(c, c->o_si.reserve(N)); HIPC(c, c->o_cri.reserve(N)); }
+    }
     HIPC(c, c->o_sw.reserve(N)); HIPC(c, c->o_sg.reserve(N));
-    if (rip) { HIPC(c, c->o_pi.reserve(N)); HIPC(c, c->o_si.reserve(N)); HIPC(c, c->o_cri.reserve(N)); }
     if (dbg_counts) {
         HIPC(c, c->o_counts.reserve(N * size_t(c->nprof)));
         HIPC(c, hipMemsetAsync(c->o_counts.p, 0, N * size_t(c->nprof) * 4, c->stream));
@@ -1502,9 +1526,19 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
     P.kmin = c->kmin; P.kmax = c->kmax; P.w = w; P.inc = inc; P.flags = flags; P.c0 = c0; P.c1 = c1;
     P.orphan_cap = int32_t(c->plan_maxwin / 8 + 2);
     P.nprof = int32_t(c->nprof);
-    P.seq_index = c->o_seq.p; P.start = c->o_start.p; P.stop = c->o_stop.p; P.status = c->o_status.p;
-    P.kld = c->o_kld.p; P.gc = c->o_gc.p; P.sw = c->o_sw.p; P.sg = c->o_sg.p;
-    P.pi = rip ? c->o_pi.p : nullptr; P.si = rip ? c->o_si.p : nullptr; P.cri = rip ? c->o_cri.p : nullptr;
+    if (packed_rows) {
+        double* b = c->o_block.p;
+        P.start = reinterpret_cast<int64_t*>(b); P.stop = reinterpret_cast<int64_t*>(b + Np); P.kld = b + 2 * Np; P.gc = b + 3 * Np;
+        double* q = b + 4 * Np;
+        P.pi = rip ? q : nullptr; P.si = rip ? q + Np : nullptr; P.cri = rip ? q + 2 * Np : nullptr;
+        q += rip ? 3 * Np : 0;
+        P.seq_index = reinterpret_cast<int32_t*>(q); P.status = reinterpret_cast<uint32_t*>(q) + Np;
+    } else {
+        P.seq_index = c->o_seq.p; P.start = c->o_start.p; P.stop = c->o_stop.p; P.status = c->o_status.p;
+        P.kld = c->o_kld.p; P.gc = c->o_gc.p;
+        P.pi = rip ? c->o_pi.p : nullptr; P.si = rip ? c->o_si.p : nullptr; P.cri = rip ? c->o_cri.p : nullptr;
+    }
+    P.sw = c->o_sw.p; P.sg = c->o_sg.p;
     P.dbg_counts = dbg_counts ? c->o_counts.p : nullptr;
     P.dbg_meta = dbg_meta ? c->o_meta.p : nullptr;
     P.dbg_ivom = nullptr;
@@ -1517,6 +1551,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
     P.stamps = nullptr;
     P.rc_tab = c->d_rctab.p; P.in_list = nullptr; P.in_count = nullptr; P.out_list = nullptr; P.out_count = nullptr;
     P.sel_mode = 0; P.sel_mod = 16; P.queue = nullptr; P.queue_n = 1; P.slide_pp = 0; P.ig_ring = nullptr;
+    P.verdict = nullptr; P.my_form = 0u;
     c->scan_stat[0] = 16; c->scan_stat[1] = 0; c->scan_stat[2] = 0; c->scan_stat[3] = 1; c->scan_stat[4] = 0;
 #ifdef FRISK_STAMPS
     DevBuf<unsigned long long> d_stamps;
@@ -1579,20 +1614,25 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
     // rows [r0, r1) to the caller's buffers
     auto copy_rows = [&](int64_t r0, int64_t r1, hipStream_t st) -> int {
         const size_t m = size_t(r1 - r0);
-        HIPC(c, hipMemcpyAsync(seq_index + r0, c->o_seq.p + r0, m * 4, hipMemcpyDeviceToHost, st));
-        HIPC(c, hipMemcpyAsync(start + r0, c->o_start.p + r0, m * 8, hipMemcpyDeviceToHost, st));
-        HIPC(c, hipMemcpyAsync(stop + r0, c->o_stop.p + r0, m * 8, hipMemcpyDeviceToHost, st));
-        HIPC(c, hipMemcpyAsync(status + r0, c->o_status.p + r0, m * 4, hipMemcpyDeviceToHost, st));
-        HIPC(c, hipMemcpyAsync(kld + r0, c->o_kld.p + r0, m * 8, hipMemcpyDeviceToHost, st));
-        HIPC(c, hipMemcpyAsync(gc + r0, c->o_gc.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+        if (packed_rows) {              // (always the whole scan: short scans run in one segment) - unpacked behind the final wait
+            HIPC(c, hipMemcpyAsync(c->h_block, c->o_block.p, blk_words * 8, hipMemcpyDeviceToHost, st));
+            return FRISK_OK;
+        }
+        HIPC(c, hipMemcpyAsync(seq_index + r0, P.seq_index + r0, m * 4, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(start + r0, P.start + r0, m * 8, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(stop + r0, P.stop + r0, m * 8, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(status + r0, P.status + r0, m * 4, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(kld + r0, P.kld + r0, m * 8, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(gc + r0, P.gc + r0, m * 8, hipMemcpyDeviceToHost, st));
         if (rip) {
-            HIPC(c, hipMemcpyAsync(pi + r0, c->o_pi.p + r0, m * 8, hipMemcpyDeviceToHost, st));
-            HIPC(c, hipMemcpyAsync(si + r0, c->o_si.p + r0, m * 8, hipMemcpyDeviceToHost, st));
-            HIPC(c, hipMemcpyAsync(cri + r0, c->o_cri.p + r0, m * 8, hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(pi + r0, P.pi + r0, m * 8, hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(si + r0, P.si + r0, m * 8, hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(cri + r0, P.cri + r0, m * 8, hipMemcpyDeviceToHost, st));
         }
         return FRISK_OK;
     };
     bool rows_sent = false;                 // the narrow-counter path finishes and ships its rows itself, in two segments
+    bool verdict_pending = false;           // the adaptive width's verdict was taken on the device in this scan: read back at the end
     unsigned int novf[34] = {0}, novf_sample[2] = {0, 0};
     HIPC(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e = hipSuccess;
@@ -1625,7 +1665,17 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         // chunks of 16 consecutive windows where the tables slide and the genome-side values travel through the ring (one window
         // in 16 is counted - and gathered - afresh; measured on the bench shard: 8: 6.71 ms, 12: 6.65, 16: 6.61, 24: 6.79), of 8 otherwise
         const bool can_slide = 2 * int64_t(inc) <= int64_t(w) - (c->kmax - 1) && !tune_env("FRISK_NO_SLIDE");
-        int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), can_slide ? 16 : 8));
+#ifndef FRISK8_CHUNK_LONG
+#define FRISK8_CHUNK_LONG 16
+#endif
+        // (a long scan can afford longer chunks - fewer windows counted and gathered afresh - while every workgroup still gets FRISK8_CHUNK_ROUNDS of them)
+        int64_t chunk_cap = can_slide ? 16 : 8;
+        if (can_slide && FRISK8_CHUNK_LONG > 16) chunk_cap = std::max<int64_t>(16, std::min<int64_t>(FRISK8_CHUNK_LONG, n / (int64_t(c->num_cu) * 3 * 64)));
+        int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), chunk_cap));
+        // (2 048 .. 12 287 windows - BASELINE's C3, a rank's share of a small genome - in chunks of two: every second window slides and reads
+        //  the ring.  Measured on C3, 12 063 windows: window by window 310 us, chunks of 2: 279, of 8: 277, of 16 - one round of the
+        //  launch's workgroups, all in step - 384; 6 000 windows: 165 / 152 / 224 / 309 - tools/exp/c3_sweep.py)
+        if (can_slide && chunk8 < 2 && n >= 2048) chunk8 = 2;
         if (flags & FRISK_SCAN_CHUNKS) chunk8 = 8;
         if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk8 = std::max<int64_t>(1, std::atoll(ev));
         // inside a chunk the order-K table slides from window to window where two windows share more than half their bases
@@ -1655,6 +1705,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         bool side = false;              // 4-bit bulk with the side table (scan8_kernel.h, SIDE)
         const bool side_ok = narrow8 && !debug;
         int sel_mode = 0;
+        bool undecided = false;         // the sample's verdict is on the device: all three bulk forms are queued, one of them runs
         frisk_ctx::Batch& RB = c->b();
         const bool hinted = RB.width_hint != 0 && RB.hint_w == w && RB.hint_inc == inc;
         if (narrow7) { /* 8-bit bulk, no sample */ }
@@ -1667,21 +1718,21 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             if (dealt) { S.queue = c->d_ovf_count.p + 8; S.queue_n = 8; }
             const int64_t nsample = (nchunks + S.sel_mod - 1) / S.sel_mod;
             HIPC(c, launch_narrow(c->kmax, 4, small_w, false, S, c->num_cu, nsample, c->stream, true));
-            unsigned int sampled[4] = {0, 0, 0, 0};     // handed on; -; (side-table form) scored, but a plain 4-bit counter would have wrapped; scored
-            HIPC(c, hipMemcpyAsync(sampled, c->d_ovf_count.p, sizeof(sampled), hipMemcpyDeviceToHost, c->stream));
-            HIPC(c, hipStreamSynchronize(c->stream));
-            const unsigned int handed = sampled[0];
+            // The verdict is taken ON THE DEVICE (scan8_decide_kernel, one thread behind the sample): the host queues all three bulk forms
+            // behind it, each with the verdict's address and its own number, and two of them return at once - no host synchronisation
+            // in the first scan of a batch (round 3: sample -> copy -> hipStreamSynchronize -> decide -> launch).  The rule:
             // 4-bit pays while fewer than about three windows in ten have to be redone (round 3, bench shard with simple repeats at
             // 0.05 / 0.1 / 0.2 / 0.3 per kb = 10 / 20 / 37 / 51 % of the scored windows handed on: 4-bit bulk 7.27 / 7.96 / 8.97 /
-            // 9.98 ms, 8-bit bulk 8.51 / 8.57 / 8.71 / 8.78 ms - tools/exp/width_sweep.sh)
-            bulk = (double(handed) <= 0.3 * double(nsample * chunk8)) ? 4 : 8;
-            // ... and the side table pays when the plain form would hand on more than FRISK_SIDE_SHARE of the windows that are scored
-            // (measured on the bench shard: it costs a scored window 1.0 ns - ten instructions per position: 6.97 against 6.59 ms per
-            // scan -, a window handed on 18 ns - a skeleton and a second scoring without sliding: tools/exp/side_rate.py)
-            side = bulk == 4 && side_ok && double(handed + sampled[2]) > FRISK_SIDE_SHARE * double(handed + sampled[3]);
-            if (const char* ev = tune_env("FRISK_SIDE")) side = side_ok && bulk == 4 && std::atoi(ev) != 0;
+            // 9.98 ms, 8-bit bulk 8.51 / 8.57 / 8.71 / 8.78 ms - tools/exp/width_sweep.sh); the side table pays when the plain form
+            // would hand on more than FRISK_SIDE_SHARE of the windows that are scored (it costs a scored window 1.0 ns - ten
+            // instructions per position: 6.97 against 6.59 ms per scan -, a window handed on 18 ns: tools/exp/side_rate.py)
+            scan8_decide_kernel<<<1, 1, 0, c->stream>>>(c->d_ovf_count.p, static_cast<unsigned int>(nsample * chunk8), double(FRISK_SIDE_SHARE),
+                                                        side_ok ? 1 : 0, c->d_verdict.p);
+            HIPC(c, hipGetLastError());
+            undecided = true;
+            verdict_pending = true;
+            bulk = 4;                           // (what the launch shapes below assume until the verdict is read back)
             sel_mode = 2;
-            RB.width_hint = bulk; RB.hint_w = w; RB.hint_inc = inc; RB.hint_side = side ? 1 : 0;
             // the sample's own hand-overs now (list 1 -> 8-bit -> list 2 -> 16-bit), so that lists and counters are free for
             // the bulk segments and no later pass touches rows of another segment
             ScanParams H = P;
@@ -1722,6 +1773,17 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
             if (dealt) { B.queue = cnt + 8; B.queue_n = 8; }
             const int64_t mchunks = (m + chunk8 - 1) / chunk8;
             const int64_t bulk_chunks = sel_mode == 2 ? mchunks - (mchunks + B.sel_mod - 1) / B.sel_mod : mchunks;
+            if (undecided) {                        // plain 4-bit / 4-bit + side table / 8-bit: the device's verdict lets one of them run
+                B.verdict = c->d_verdict.p;
+                B.out_list = list1; B.out_count = cnt;
+                B.my_form = 1u;
+                HIPC(c, launch_narrow(c->kmax, 4, small_w, false, B, c->num_cu, bulk_chunks, st, false, false));
+                B.my_form = 2u;
+                HIPC(c, launch_narrow(c->kmax, 4, small_w, false, B, c->num_cu, bulk_chunks, st, false, true));
+                B.my_form = 3u;
+                B.out_list = list2; B.out_count = cnt + 1;
+                HIPC(c, launch_narrow(c->kmax, 8, small_w, false, B, c->num_cu, bulk_chunks, st));
+            } else
             HIPC(c, launch_narrow(c->kmax, bulk, small_w, debug, B, c->num_cu, bulk_chunks, st, false, side));
             if (bulk == 4) {                        // list 1 (4-bit hand-overs) -> 8-bit -> list 2
                 ScanParams H = R;
@@ -1820,8 +1882,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
 #endif
     if (!rows_sent) {
         if (c->plan_maxwin <= 65535 && c->kmax <= 8 && n > 0) {     // the LDS kernels leave the rows' scalar tail to one thread per row
-            finish_rows_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(n, c->o_status.p, c->o_kld.p, c->o_gc.p, c->o_sw.p,
-                                                                                c->o_sg.p);
+            finish_rows_kernel<<<grid_for(n, 256, 1 << 20), 256, 0, c->stream>>>(n, P.status, P.kld, P.gc, P.sw, P.sg);
             HIPC(c, hipGetLastError());
         }
         HIPC(c, hipEventRecord(c->ev1, c->stream));
@@ -1833,7 +1894,22 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
     if (dbg_meta) HIPC(c, hipMemcpyAsync(dbg_meta, c->o_meta.p, N * 3 * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->want_ivom) HIPC(c, hipMemcpyAsync(c->want_ivom, c->o_ivom.p, N * 2 * nk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (narrow) HIPC(c, hipMemcpyAsync(novf, c->d_ovf_count.p, sizeof(novf), hipMemcpyDeviceToHost, c->stream));
+    unsigned int verdict_host[4] = {0, 0, 0, 0};
+    if (verdict_pending) HIPC(c, hipMemcpyAsync(verdict_host, c->d_verdict.p, sizeof(verdict_host), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (verdict_pending) {              // what the device decided: remembered per batch and geometry (later scans launch that form alone)
+        frisk_ctx::Batch& VB = c->b();
+        VB.width_hint = verdict_host[0] == 3u ? 8 : 4; VB.hint_w = w; VB.hint_inc = inc; VB.hint_side = verdict_host[0] == 2u ? 1 : 0;
+        c->scan_stat[0] = VB.width_hint;
+        c->scan_stat[4] = VB.hint_side;
+    }
+    if (packed_rows) {
+        const double* b = static_cast<const double*>(c->h_block);
+        std::memcpy(start, b, N * 8); std::memcpy(stop, b + Np, N * 8); std::memcpy(kld, b + 2 * Np, N * 8); std::memcpy(gc, b + 3 * Np, N * 8);
+        const double* q = b + 4 * Np;
+        if (rip) { std::memcpy(pi, q, N * 8); std::memcpy(si, q + Np, N * 8); std::memcpy(cri, q + 2 * Np, N * 8); q += 3 * Np; }
+        std::memcpy(seq_index, q, N * 4); std::memcpy(status, reinterpret_cast<const uint32_t*>(q) + Np, N * 4);
+    }
     c->scan_stat[1] = novf[0] + novf[32] + novf_sample[0];
     c->scan_stat[2] = novf[1] + novf[33] + novf_sample[1];
     if (c->b().tiled)               // descriptor index -> index of the scaffold in the FASTA

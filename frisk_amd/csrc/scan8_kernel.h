@@ -63,7 +63,10 @@
 #ifndef FRISK8_PARK_LATE
 #define FRISK8_PARK_LATE 0          // 1: a parking wave stores behind its scoring loop instead of inside it (measured: +-0)
 #endif
-#define FRISK8_RING_COLS 512        // ring geometry: ITS rows x 512 columns of doubles per workgroup (position p <-> row p % ITS, column p / ITS % 512)
+#ifndef FRISK8_RING_COLS
+#define FRISK8_RING_COLS 256        // ring geometry: ITS rows x 256 columns of doubles per workgroup (position p <-> row p % ITS, column p / ITS % 256):
+#endif                              // ITS x 256 = the most positions a window of this instantiation has - 40 KB per workgroup at 20 positions per lane
+                                    // (round 3 had 512 columns, 80 KB: the same time, twice the footprint beside 4 MB of L2 per XCD)
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
 enum { M8_NPLACED = 1,             // misc slots (0, 2, 4, 5: M_UPA, M_UPG, M_NORPH, M_NVALID): orphans folded into the order-K table ...
@@ -129,6 +132,20 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
     x = dpp_addu<0xB1>(x); x = dpp_addu<0x4E>(x); x = dpp_addu<0x141>(x); x = dpp_addu<0x140>(x);
     return __builtin_amdgcn_readlane(int(x), 0) + __builtin_amdgcn_readlane(int(x), 16) +
            __builtin_amdgcn_readlane(int(x), 32) + __builtin_amdgcn_readlane(int(x), 48);
+}
+
+// The adaptive width's verdict, on the device (one thread, behind the sample launch): which form scores the rest of the scan.
+// counts[0] = sampled windows handed on anyway, [2] = scored, but a plain 4-bit counter would have wrapped, [3] = scored;
+// n_sampled = windows in the sample.  The rule is frisk_abi.hip's (measured break-evens there): 8-bit bulk when more than three
+// sampled windows in ten overflow 4 bits anyway; else the side table when the plain form would hand on more than side_share of
+// the windows that are scored.  verdict[0] = 1 plain 4-bit, 2 4-bit + side table, 3 8-bit; verdict[1..3] = the three counts (for
+// the host's statistics, read at the end of the scan).
+__global__ void scan8_decide_kernel(const unsigned int* __restrict__ counts, unsigned int n_sampled, double side_share, int side_ok,
+                                    unsigned int* __restrict__ verdict) {
+    const unsigned int handed = counts[0], would = counts[2], scored = counts[3];
+    unsigned int form = (double(handed) <= 0.3 * double(n_sampled)) ? 1u : 3u;
+    if (form == 1u && side_ok && double(handed + would) > side_share * double(handed + scored)) form = 2u;
+    verdict[0] = form; verdict[1] = handed; verdict[2] = would; verdict[3] = scored;
 }
 
 // ROLE names the launch (bit 0: the sample of the adaptive width, bit 1: no sliding, hence no ring): the code is otherwise the same, but a profiler's
@@ -232,6 +249,8 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     };
     // (a launch over a hand-over list finds it empty nearly always: nothing to set up)
     if (P.in_list != nullptr && *P.in_count == 0u) return;
+    // (the first scan of a batch queues all three bulk forms behind its sample; the sample's verdict, on the device, picks one)
+    if (P.verdict != nullptr && *P.verdict != P.my_form) return;
 #if FRISK8_PRIO
     __builtin_amdgcn_s_setprio(FRISK8_PRIO);
 #endif

@@ -86,6 +86,8 @@ struct ScanParams {
     unsigned int* queue;          // scan8_kernel: != nullptr: chunks are dealt by these counters (zero at launch) instead of by block index:
     int32_t queue_n;              // ... queue_n (1 or 8) of them, one per XCD, each over a contiguous share of the chunks
     double* ig_ring;              // scan8_kernel: per-workgroup ring of genome-side values by window position (see scan8_kernel.h), or nullptr
+    const unsigned int* verdict;  // scan8_kernel: != nullptr: this launch runs only if *verdict == my_form (the adaptive width's sample decides on the
+    unsigned int my_form;         // ... device which of the bulk forms - 1 plain 4-bit, 2 4-bit + side table, 3 8-bit - scores the rest; the others return at once)
     int32_t slide_pp;             // scan8_kernel: > 0: inside a chunk the order-K table slides from window to window, this many positions of
                                   // the leaving and of the entering range per thread (= ceil(inc / threads)); 0: every window counted afresh
 };

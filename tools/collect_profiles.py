@@ -22,21 +22,33 @@ if os.path.exists(kt):
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
         w.writeheader()
         w.writerows(hot[-24:])
-# staged upload: H2D copies against the kernels, last steps of the run (rocprofv3 --kernel-trace --memory-copy-trace)
+# streamed upload (tools/stream_job.py under rocprofv3 --kernel-trace --memory-copy-trace): the H2D pieces of ONE job against
+# the kernels that follow them - expand_runs, one profile_add_kernel per piece, finalize, the scan
 mc, uk = os.path.join(src, "upload_memory_copy_trace.csv"), os.path.join(src, "upload_kernel_trace.csv")
 if os.path.exists(mc) and os.path.exists(uk):
-    copies = [r for r in csv.DictReader(open(mc)) if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 200000]
-    kern = [r for r in csv.DictReader(open(uk)) if any(k in r["Kernel_Name"] for k in ("scan8_kernel", "profile_add", "pack_kernel"))
-            and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 100000]
-    t0 = min(int(r["Start_Timestamp"]) for r in copies + kern)
-    ev = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, "H2D copy (stream %s)" % r["Stream_Id"]) for r in copies if "HOST_TO_DEVICE" in r["Direction"]]
-    ev += [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Kernel_Name"].split("(")[0][:48]) for r in kern]
-    ev.sort()
-    with open(os.path.join(dst, name + "_upload_overlap.txt"), "w") as fh:
-        fh.write("# rocprofv3 --kernel-trace --memory-copy-trace -- python3 bench.py --steps 3 --warmup 1 --cpu-windows 0\n"
-                 "# last 30 events >= 0.1 ms: the `pipelined_ascii` phase - frisk_seq_stage's H2D copies (410 MB per step, copy stream)\n"
-                 "# run WHILE profile_add / scan8_kernel of the resident batch run (compute stream); pack_kernel follows the copies.\n"
-                 "#   start [ms]   duration [ms]   what\n")
-        for a, b, what in ev[-30:]:
-            fh.write("%12.3f   %10.3f   %s\n" % (a / 1e6, (b - a) / 1e6, what))
+    copies = [r for r in csv.DictReader(open(mc)) if "HOST_TO_DEVICE" in r["Direction"]]
+    kern = [r for r in csv.DictReader(open(uk)) if any(k in r["Kernel_Name"] for k in ("scan8_kernel", "profile_add", "expand_runs", "genome_ivom", "finish_rows"))]
+    big = [r for r in copies if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 100000]
+    # the last job: from the first big copy behind the last-but-one scan to the end of the last scan
+    scans = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in kern if "scan8_kernel" in r["Kernel_Name"]
+                   and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 5000000)
+    if len(scans) >= 2 and big:
+        lo = scans[-2][1]
+        t0 = min(int(r["Start_Timestamp"]) for r in big if int(r["Start_Timestamp"]) > lo)
+        ev = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, "H2D copy, %d bytes" % int(r.get("Bytes", r.get("Size", 0)) or 0))
+              for r in copies if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 20000]
+        ev += [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Kernel_Name"].split("(")[0][:60]) for r in kern
+               if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 20000]
+        ev.sort()
+        under = sum(1 for a, b, w in ev if w.startswith("void profile_add") or w.startswith("profile_add"))
+        with open(os.path.join(dst, name + "_stream_overlap.txt"), "w") as fh:
+            fh.write("# rocprofv3 --kernel-trace --memory-copy-trace -- python3 tools/stream_job.py 3   (one whole C5-shaped job, 0.25 B/base form)\n"
+                     "# the LAST job of the run, every event >= 0.02 ms, t = 0 at its first big H2D copy: the codes cross PCIe in 16 MB pieces\n"
+                     "# (copy stream) while one profile_add_kernel per piece runs on the compute stream behind its piece's event; only the\n"
+                     "# last piece's kernel, finalize and the scan follow the upload.  %d profile_add launches in this job.\n"
+                     "#   start [ms]   duration [ms]   what\n" % under)
+            for a, b, what in ev:
+                fh.write("%12.3f   %10.3f   %s\n" % (a / 1e6, (b - a) / 1e6, what))
+    if os.path.exists(os.path.join(src, "stream_job.json")):
+        shutil.copy(os.path.join(src, "stream_job.json"), os.path.join(dst, name + "_stream_job.json"))
 print("copied to", dst)
