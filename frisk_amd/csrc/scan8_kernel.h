@@ -284,6 +284,10 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     // Which candidates: the chunks of [c0, c1) - all of them (sel_mode 0), every sel_mod-th (1: the sample that decides the
     // counter width for the rest), all but those (2) - or, one at a time, the windows a narrower form handed over (in_list).
+    // (a launch over a hand-over list takes its windows one by one, in the order they were appended.  Walking a LONG list in
+    //  candidate order instead - the launch going through the range in chunks and scoring the windows flagged as handed on, so that
+    //  the runs a satellite array hands over slide - was built in round 4 and measured slower: 8.05 against 7.43 ms per scan of
+    //  the shard with 3 % satellite arrays, 40 804 windows handed on; NOTES.md)
     const bool listed = P.in_list != nullptr;
     const int64_t chunk = listed ? 1 : P.chunk;
     const int64_t nall = listed ? int64_t(*P.in_count) : (P.c1 - P.c0 + chunk - 1) / chunk;

@@ -131,3 +131,32 @@ def test_some_windows_overflowed_four_bits():
     if SIDED:
         with_side, plain = sum(a for a, _ in SIDED), sum(b for _, b in SIDED)
         assert with_side < plain, (with_side, plain)
+
+
+def test_long_handover_lists_of_satellite_arrays():
+    """Satellite arrays hand EVERY window they cover from the 4-bit to the 8-bit form: thousands of list entries in runs of
+    consecutive windows.  Same rows as the C oracle for every window, and as scans of sub-ranges (short lists), bit for bit."""
+    from oracle import frisk_oracle_c as OC
+    from frisk_amd import Engine
+    lens = [9_000_000, 2_500_000]
+    kw = dict(island_frac=0.02, n_frac=0.03, lower_frac=0.0, repeats_per_kb=0.35, period_mix=0.25, sat_frac=0.25)
+    with Engine(1, 8) as e:
+        e.synth(lens, seed=77, **kw)
+        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        res = e.scan(5000, 1000, rip=True, bits4=True)
+        handed8, handed16 = e.scan_stat()[1:3]
+        n = len(res)
+        assert handed8 > max(1024, n // 48), (handed8, n)
+        S = OC.Seqs([e.read_seq(q) for q in range(len(lens))])
+        osym, ometa = OC.genome_profile(S, 1, 8)
+        exp = OC.scan(S, OC.genome_ivom(osym, ometa, 1, 8), 1, 8, 5000, 1000, rip=True)
+        k = np.nonzero(res.kept)[0]
+        assert len(k) == len(exp["kld"]) and np.array_equal(res.start[k], exp["start"]) and np.array_equal(res.gc[k], exp["gc"])
+        assert np.max(np.abs(res.kld[k] - exp["kld"])) <= 1e-11
+        for col in ("pi", "si", "cri"):
+            assert np.array_equal(getattr(res, col)[k], exp[col], equal_nan=True)
+        step = 700
+        for c0 in range(0, min(n, 5600), step):
+            part = e.scan(5000, 1000, rip=True, bits4=True, c0=c0, c1=min(n, c0 + step))
+            for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):
+                assert np.array_equal(getattr(part, f), getattr(res, f)[c0:c0 + step], equal_nan=True), (f, c0)
