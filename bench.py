@@ -494,7 +494,7 @@ def main(argv=None):
             "windowed_gbases_per_s": rows_all * W / (elapsed / opts.steps) / 1e9,      # rows x w: bases looked at, overlap counted
             "scan_kernel_ms": scan_avg, "profile_kernel_ms": sum(prof_ms) / len(prof_ms),
             # (the timed steps one by one: the GPU's clocks are still rising through the first steps behind the input generator's
-            #  small launches - the first scan of a fresh batch is 0.85 ms slower than the third even without the sample)
+            #  small launches - the first scan of a fresh batch is ~1.2 ms slower than the fourth even without the sample: the GPU leaving an idle power state, NOTES.md round 4)
             "scan_kernel_ms_first_min_last": [scan_ms[0], min(scan_ms), scan_ms[-1]],
             "scan_kernel_windows_per_s": n_cand / (scan_avg * 1e-3),
             "scan_counter_width": {"bulk_bits": width, "side_table_for_period4_maxmers": side_table, "windows_handed_to_8bit": handed8,
@@ -515,7 +515,7 @@ def main(argv=None):
                                           "a tail of whole rounds of workgroups on a second stream): its 'average' there is their mean, the scan is their sum",
                          "note": "formal bound only: the path is not HBM-limited at any plausible rate (290 B/window, "
                                  "HBM-bound ceiling 2.7e10 windows/s); what binds is in `binding` and `l2_gather`"},
-            # what did bind until round 3: every scored position reads 8 bytes of the 512 KB genome table at a random
+            # what did bind until round 3 (NOTES.md 3.3a): every scored position reads 8 bytes of the 512 KB genome table at a random
             # place = one 128-byte line from L2.  Modelled line traffic of one scan, before and with the ring (a position's value is
             # gathered once per chunk of 16 windows and otherwise read coalesced from the workgroup's ring)
             "l2_gather": (lambda pos, chunk: {

@@ -35,7 +35,7 @@ if os.path.exists(mc) and os.path.exists(uk):
     if len(scans) >= 2 and big:
         lo = scans[-2][1]
         t0 = min(int(r["Start_Timestamp"]) for r in big if int(r["Start_Timestamp"]) > lo)
-        ev = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, "H2D copy, %d bytes" % int(r.get("Bytes", r.get("Size", 0)) or 0))
+        ev = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, "H2D copy (copy stream; the big ones: 16 MB pieces of the 2-bit codes)")
               for r in copies if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 20000]
         ev += [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Kernel_Name"].split("(")[0][:60]) for r in kern
                if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 20000]
