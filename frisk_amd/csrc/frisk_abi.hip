@@ -1687,7 +1687,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         if (narrow8 && (P.slide_pp > 0 || debug)) {
             const size_t slices = size_t(std::min<int64_t>(std::max<int64_t>((n + chunk8 - 1) / chunk8, 1), int64_t(c->num_cu) * 4));
             const double* had = c->d_ig_ring.p;
-            HIPC(c, c->d_ig_ring.reserve(nk + slices * 20 * FRISK8_RING_COLS));
+            HIPC(c, c->d_ig_ring.reserve(nk + slices * (20 * FRISK8_RING_COLS + FRISK8_RING_PAD)));
             if (c->d_ig_ring.p != had || c->ring_gen != c->ig_gen) {        // (once per genome table, not once per scan)
                 HIPC(c, hipMemcpyAsync(c->d_ig_ring.p, c->d_ig.p, nk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
                 c->ring_gen = c->ig_gen;

@@ -67,6 +67,7 @@
 #define FRISK8_RING_COLS 256        // ring geometry: ITS rows x 256 columns of doubles per workgroup (position p <-> row p % ITS, column p / ITS % 256):
 #endif                              // ITS x 256 = the most positions a window of this instantiation has - 40 KB per workgroup at 20 positions per lane
                                     // (round 3 had 512 columns, 80 KB: the same time, twice the footprint beside 4 MB of L2 per XCD)
+#define FRISK8_RING_PAD 16          // doubles behind every workgroup's slice of the ring (see dummy_off)
 #define FRISK8_SLOTS 8             // misc counters per window (double-buffered by window parity)
 
 enum { M8_NPLACED = 1,             // misc slots (0, 2, 4, 5: M_UPA, M_UPG, M_NORPH, M_NVALID): orphans folded into the order-K table ...
@@ -332,7 +333,11 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
     // (one buffer: a copy of the genome table first, the workgroups' slices behind it - so that "from the table" and "from the
     //  ring" are two 32-bit offsets from one base, and the scoring loop's load is one instruction either way)
     char* const ring = RING ? reinterpret_cast<char*>(P.ig_ring) : nullptr;
-    const uint32_t slice_off = RING ? uint32_t((size_t(NK) + size_t(blockIdx.x) * size_t(ITS) * FRISK8_RING_COLS) * 8) : 0u;
+    // (a workgroup's slice: ITS x COLS doubles, then FRISK8_RING_PAD doubles that nobody reads - where the lanes of a parking wave that
+    //  gathered nothing send their store: an unconditional store with a selected address keeps the scoring loop one scheduling region,
+    //  a store under a per-lane condition put a branch behind every position and made the scan 2.6 x slower)
+    const uint32_t slice_off = RING ? uint32_t((size_t(NK) + size_t(blockIdx.x) * (size_t(ITS) * FRISK8_RING_COLS + FRISK8_RING_PAD)) * 8) : 0u;
+    const uint32_t dummy_off = slice_off + uint32_t(ITS) * FRISK8_RING_COLS * 8u;
     bool slide_next = false;            // the table is left standing for the next window (which slides); false: it is cleared
     bool ring_next = false;             // ... and so is the ring: the window before this one went through the scoring loop (a window
                                         // that the N filter drops, or that is handed on, parks nothing - its successor gathers afresh)
@@ -446,16 +451,27 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             // where the window's first base sits in the ring: row rb_r, column rb_q (uniform)
             const uint32_t ring_base = RING ? uint32_t(uint64_t(st) % uint64_t(ITS * FRISK8_RING_COLS)) : 0u;
             const uint32_t rb_q = ring_base / uint32_t(ITS), rb_r = ring_base - rb_q * uint32_t(ITS);
+            // WHICH positions a lane holds.  Block b = positions [b ITS, (b + 1) ITS) of the window; lane t holds block t.  FRISK8_DEAL = 1
+            // (round 4, measured and NOT taken) deals the blocks to the four waves in groups of sixteen - wave w holds the groups w,
+            // w + 4, w + 8, w + 12 - so that the entering range of a slid window (the lanes that gather from the genome table, a cache
+            // line per lane, and park) is shared by all four waves (9 / 16 / 16 / 10 lanes at w = 5000, inc = 1000) instead of sitting
+            // in wave 3 (57 lanes) with the other three waiting at the loop's barrier.  But then every wave runs the parking copy of
+            // the scoring loop: 6.30-6.35 ms per scan of the bench shard against 6.13-6.17 (stores behind the loop: 6.21-6.31), and
+            // with the store under a per-lane condition - a branch behind every position - 16.1 ms.
+#ifndef FRISK8_DEAL
+#define FRISK8_DEAL 0
+#endif
+            const int blk = (FRISK8_DEAL && NT == 256) ? ((((tid & 63) >> 4) * 4 + (tid >> 6)) * 16 + (tid & 15)) : tid;
             // byte offset (from the buffer's base) of the ring's place for this lane's it-th position
             auto ring_mine = [&](int it) __attribute__((always_inline)) -> uint32_t {
                 const uint32_t rr = rb_r + uint32_t(it);                         // (uniform: the row, and whether it wraps into the next column)
                 const uint32_t cy = rr >= uint32_t(ITS) ? 1u : 0u;
-                return slice_off + ((((rr - cy * uint32_t(ITS)) * FRISK8_RING_COLS) + ((rb_q + cy + uint32_t(tid)) & (FRISK8_RING_COLS - 1u))) << 3);
+                return slice_off + ((((rr - cy * uint32_t(ITS)) * FRISK8_RING_COLS) + ((rb_q + cy + uint32_t(blk)) & (FRISK8_RING_COLS - 1u))) << 3);
             };
             const bool sliding = slide_next;
             // this lane gathers its positions' genome-side values from the table (and parks them in the ring): every lane of a
             // window counted afresh, the lanes that hold a position of the entering range in a window slid into
-            const bool lane_new = !sliding || !ring_next || tid * ITS + (ITS - 1) >= P.w - (K - 1) - P.inc;
+            const bool lane_new = !sliding || !ring_next || blk * ITS + (ITS - 1) >= P.w - (K - 1) - P.inc;
             ring_next = false;                                  // (true again where this window's scoring loop has run)
             slide_next = slide_pp > 0 && ci + 1 < ce && d.kind == 0 && !jump && cand + 1 < d.cand0 + d.ncand &&
                          st + int64_t(P.inc) + P.w <= d.size;
@@ -471,7 +487,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
             parity ^= 1u;
 
             // ---- stage 1: one pass over the window's positions (a lane owns ITS consecutive ones) -----------
-            const int j0 = tid * ITS;
+            const int j0 = blk * ITS;
             const int64_t gl = g0 + (j0 < n ? j0 : 0);                       // clamped: loads are unconditional
             const int64_t wi = gl >> 4, mi = gl >> 5;
             const int shc = 32 - int(gl & 15) * 2, shm = 32 - int(gl & 31);
@@ -1289,7 +1305,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                             if constexpr (PARK) {
                                 const double v = on_at(g + k) ? f[k].Ig : 1.0;
                                 if constexpr (PARK_LATE) parked[g + k] = v;      // (unrolled form: stored behind the loop)
-                                else *reinterpret_cast<double*>(ring + f[k].roff) = v;
+                                else *reinterpret_cast<double*>(ring + ((!FRISK8_DEAL || lane_new) ? f[k].roff : dummy_off)) = v;   // (DEAL: the lanes that gathered park; the others' values are there)
                             }
                             score_one(f[k], c8[k], c7[k], c6[k], on_at(g + k) ? c8[k] : 0u, on_at(g + k));
                         }
@@ -1330,7 +1346,7 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                 }
                 if constexpr (PARK_LATE) {
 #pragma unroll
-                    for (int it = 0; it < ITS; ++it) *reinterpret_cast<double*>(ring + ring_mine(it)) = parked[it];
+                    for (int it = 0; it < ITS; ++it) *reinterpret_cast<double*>(ring + ((!FRISK8_DEAL || lane_new) ? ring_mine(it) : dummy_off)) = parked[it];
                 }
             };
             constexpr uint32_t ALL_MINE = uint32_t(0xFFFFFFFF00000000ull >> ITS);

@@ -75,6 +75,18 @@ def test_profile_follows_the_pieces_and_rows_match(piece_bases, kmax):
         e.load(seqs)
         ref = run(e)
         codes, ri, rl, lens = e.pack_2bit(seqs)
+        if kmax == 8 and piece_bases == 4096:                # ... and the rows are the ORACLE's (numpy restatement, pinned to the reference's goldens)
+            from oracle import frisk_oracle_np as N
+            prof = N.genome_profile(seqs, 1, 8)
+            want = N.scan([(str(i), s) for i, s in enumerate(seqs)], prof, 1, 8, 5000, 1000, False, True)
+            e.stage_2bit(codes, ri, rl, lens, piece_bases=piece_bases)
+            e.commit()
+            raw, res = run(e)
+            k = np.nonzero(res.kept)[0]
+            assert len(k) == len(want) > 200
+            assert [(int(res.start[r]), int(res.stop[r])) for r in k.tolist()] == [(w["start"], w["stop"]) for w in want]
+            assert max(abs(float(res.kld[r]) - w["KLD"]) for r, w in zip(k.tolist(), want)) <= 1e-10
+            assert all(float(res.gc[r]) == w["GC"] for r, w in zip(k.tolist(), want))
         for _ in range(2):                                   # both batch slots
             e.stage_2bit(codes, ri, rl, lens, piece_bases=piece_bases)
             same(run(e), ref)                                # the resident batch is untouched while the upload is in flight
