@@ -46,27 +46,71 @@ inline void push_run(std::vector<int64_t>& v, int64_t b, int64_t e) {
     else { v.push_back(b); v.push_back(e); }
 }
 
+// eight letters at once (one 64-bit load, first letter in the low byte): their 2-bit codes as 16 bits with the FIRST letter most
+// significant, and the two masks as 8 bits (bit i = letter i).  Branch-free word arithmetic; classification as the table above.
+struct Eight { uint32_t code16, inv8, low8; };
+inline Eight classify8(uint64_t w) {
+    constexpr uint64_t K01 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
+    const uint64_t fold = w & 0xDFDFDFDFDFDFDFDFull;                       // ASCII case folded
+    auto zero_bytes = [&](uint64_t t) -> uint64_t { return ~(((t & K7F) + K7F) | t | K7F); };          // 0x80 in every zero byte, exactly
+    const uint64_t valid = zero_bytes(fold ^ (K01 * 'A')) | zero_bytes(fold ^ (K01 * 'C')) | zero_bytes(fold ^ (K01 * 'G')) |
+                           zero_bytes(fold ^ (K01 * 'T'));
+    const uint64_t lower = (w & 0x2020202020202020ull) << 2;               // 0x80 where the letter is lowercase
+    // (c >> 1) & 3: A 0, C 1, T 2, G 3  ->  A 0, T 1, G 2, C 3:  low' = low ^ high, high' = low
+    const uint64_t x = fold >> 1, lo = x & K01, hi = (x >> 1) & K01;
+    uint64_t cb = (((lo << 1) | (lo ^ hi)) & ((valid >> 7) * 3u));         // one code per byte, 0 where invalid
+    cb = __builtin_bswap64(cb);                                            // first letter in the top byte
+    cb = (cb | (cb >> 6)) & 0x000F000F000F000Full;                         // pairs -> nibbles
+    cb = (cb | (cb >> 12)) & 0x000000FF000000FFull;                        // -> bytes
+    cb = (cb | (cb >> 24)) & 0xFFFFull;                                    // -> 16 bits
+    auto bits8 = [](uint64_t m80) -> uint32_t { return uint32_t(((m80 >> 7) * 0x0102040810204080ull) >> 56); };     // byte i -> bit i
+    return Eight{uint32_t(cb), bits8(~valid & K80), bits8(valid & lower)};
+}
+
+// one mask of 16 positions from p on (bit i = position p + i) into a run list with an open run carried along
+inline void track16(uint32_t m, int64_t p, int64_t& open, std::vector<int64_t>& out) {
+    if ((open < 0 && m == 0u) || (open >= 0 && m == 0xFFFFu)) return;      // nothing changes inside these 16: nearly always
+    for (int i = 0; i < 16; ++i) {
+        const bool on = (m >> i) & 1u;
+        if (on) { if (open < 0) open = p + i; }
+        else if (open >= 0) { push_run(out, open, p + i); open = -1; }
+    }
+}
+
 // positions [p0, p1) of one scaffold piece: `src` = its bytes, codes written to the words of `codes` (2 bits per position,
-// big-endian in the word; the caller zeroed them), runs appended.  p0 is a multiple of 16 unless the piece starts a
-// scaffold - words shared by two pieces are written by ONE piece only because pieces are cut at multiples of 32.
+// big-endian in the word; the caller zeroed them), runs appended.  Words shared by two pieces are written by ONE thread only
+// because the threads' ranges are cut at multiples of 32.  Whole 16-position words go eight letters at a time (classify8);
+// the ragged head and tail of a piece letter by letter.
 inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* codes, Runs& out) {
     const uint8_t* T = lut().t;
     int64_t inv_b = -1, low_b = -1;
     int64_t p = p0;
     const uint8_t* s = src;
-    while (p < p1) {
-        const int64_t wend = std::min<int64_t>(p1, (p | 15) + 1);       // positions of one code word
-        uint32_t word = 0;
-        for (; p < wend; ++p, ++s) {
-            const uint32_t v = T[*s];
-            word |= (v & 3u) << (30 - 2 * int(p & 15));
-            if (v & 4u) { if (inv_b < 0) inv_b = p; }
-            else if (inv_b >= 0) { push_run(out.inv, inv_b, p); inv_b = -1; }
-            if (v & 8u) { if (low_b < 0) low_b = p; }
-            else if (low_b >= 0) { push_run(out.low, low_b, p); low_b = -1; }
+    auto letters = [&](int64_t upto) {
+        while (p < upto) {
+            const int64_t wend = std::min<int64_t>(upto, (p | 15) + 1);   // positions of one code word
+            uint32_t word = 0;
+            for (; p < wend; ++p, ++s) {
+                const uint32_t v = T[*s];
+                word |= (v & 3u) << (30 - 2 * int(p & 15));
+                if (v & 4u) { if (inv_b < 0) inv_b = p; }
+                else if (inv_b >= 0) { push_run(out.inv, inv_b, p); inv_b = -1; }
+                if (v & 8u) { if (low_b < 0) low_b = p; }
+                else if (low_b >= 0) { push_run(out.low, low_b, p); low_b = -1; }
+            }
+            codes[(p - 1) >> 4] |= word;
         }
-        codes[(p - 1) >> 4] |= word;
+    };
+    letters(std::min<int64_t>(p1, (p0 + 15) & ~int64_t(15)));              // up to the first word boundary
+    for (; p + 16 <= p1; p += 16, s += 16) {
+        uint64_t a, b;
+        std::memcpy(&a, s, 8); std::memcpy(&b, s + 8, 8);
+        const Eight x = classify8(a), y = classify8(b);
+        codes[p >> 4] |= (x.code16 << 16) | y.code16;
+        track16(x.inv8 | (y.inv8 << 8), p, inv_b, out.inv);
+        track16(x.low8 | (y.low8 << 8), p, low_b, out.low);
     }
+    letters(p1);
     if (inv_b >= 0) push_run(out.inv, inv_b, p1);
     if (low_b >= 0) push_run(out.low, low_b, p1);
 }
