@@ -1025,7 +1025,10 @@ static int upload_2bit(frisk_ctx* c, frisk_ctx::Batch& B, const uint32_t* codes,
     if (rc) return rc;
     // the codes, piece by piece: an event behind each, so that phase A can follow the copies (frisk_profile_add)
     const int64_t w32 = P / 32;
-    int64_t piece_words = (piece_bases ? piece_bases : (int64_t(1) << 26)) / 32;          // default: 64 Mbases = 16 MB of codes
+    // default: 256 Mbases = 64 MB of codes (measured on the whole C5 shape, ms per streamed job: pieces of 8 MB 71.6, 16 MB 69.2,
+    // 32 MB 67.5, 64 MB 66.6, 128 MB 66.5 - the copy engine leaves ~20 us between two copies, the last piece's profile kernel
+    // is what follows the upload: tools/exp/piece_sweep.py)
+    int64_t piece_words = (piece_bases ? piece_bases : (int64_t(1) << 28)) / 32;
     if (piece_words < 1) piece_words = 1;
     const int64_t n_pieces = std::max<int64_t>(1, (w32 + piece_words - 1) / piece_words);
     if (n_pieces > 4096) piece_words = (w32 + 4095) / 4096;

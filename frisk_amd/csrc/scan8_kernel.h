@@ -463,7 +463,25 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
 #endif
             const int blk = (FRISK8_DEAL && NT == 256) ? ((((tid & 63) >> 4) * 4 + (tid >> 6)) * 16 + (tid & 15)) : tid;
             // byte offset (from the buffer's base) of the ring's place for this lane's it-th position
+            // ... split into what is the same for every lane (the row, and the slice: scalar arithmetic, and it becomes part of the load's
+            // scalar base) and the lane's column - one of two values per window, by whether the row index wrapped (`FRISK8_RING_SPLIT`;
+            // round 3 computed row, carry, column, mask, shift and sum on the vector unit for every position: four VALU instructions
+            // of the scoring loop's ~52 per position)
+#ifndef FRISK8_RING_SPLIT
+#define FRISK8_RING_SPLIT 1
+#endif
+            const uint32_t lane_col0 = RING ? (((rb_q + uint32_t(blk)) & (FRISK8_RING_COLS - 1u)) << 3) : 0u;
+            const uint32_t lane_col1 = RING ? (((rb_q + 1u + uint32_t(blk)) & (FRISK8_RING_COLS - 1u)) << 3) : 0u;
+            auto ring_uni = [&](int it) __attribute__((always_inline)) -> uint32_t {        // (uniform) slice + row
+                const uint32_t rr = rb_r + uint32_t(it);
+                const uint32_t cy = rr >= uint32_t(ITS) ? 1u : 0u;
+                return slice_off + (((rr - cy * uint32_t(ITS)) * FRISK8_RING_COLS) << 3);
+            };
+            auto ring_lane = [&](int it) __attribute__((always_inline)) -> uint32_t {       // the lane's column, in bytes
+                return (rb_r + uint32_t(it) >= uint32_t(ITS)) ? lane_col1 : lane_col0;
+            };
             auto ring_mine = [&](int it) __attribute__((always_inline)) -> uint32_t {
+                if (FRISK8_RING_SPLIT) return ring_uni(it) + ring_lane(it);
                 const uint32_t rr = rb_r + uint32_t(it);                         // (uniform: the row, and whether it wraps into the next column)
                 const uint32_t cy = rr >= uint32_t(ITS) ? 1u : 0u;
                 return slice_off + ((((rr - cy * uint32_t(ITS)) * FRISK8_RING_COLS) + ((rb_q + cy + uint32_t(blk)) & (FRISK8_RING_COLS - 1u))) << 3);
@@ -803,7 +821,10 @@ __global__ __launch_bounds__(NT, WPS) void scan8_kernel(const ScanParams P) {
                     f.Ig = 1.0;
                     if (mode) {
                         f.roff = ring_mine(it);
-                        f.Ig = *reinterpret_cast<const double*>(ring + ((mode == 2 && lane_new) ? (c16 << 3) : f.roff));
+                        if (FRISK8_RING_SPLIT && mode == 1)      // every lane reads the ring: scalar base (slice + row) + the lane's column
+                            f.Ig = *reinterpret_cast<const double*>((ring + ring_uni(it)) + ring_lane(it));
+                        else
+                            f.Ig = *reinterpret_cast<const double*>(ring + ((mode == 2 && lane_new) ? (c16 << 3) : f.roff));
                     }
                 } else {
                 f.Ig = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P.ig) + (c16 << 3));   // c16 < 4^K always

@@ -96,7 +96,7 @@ int frisk_seq_stage_packed(frisk_ctx* ctx, const uint32_t* codes, const uint32_t
  * lists - n_inv / n_low pairs [begin, end) of padded positions, ascending and disjoint: inv = letters other than ACGTacgt,
  * low = lowercase acgt - and are expanded to the bitmaps on the device; PADs are the library's business.  n_inv (n_low) < 0:
  * the argument is the dense bitmap instead (P / 32 words, PAD bits clear) - for an assembly with more runs than bitmap words.
- * The codes cross PCIe in pieces of piece_bases positions (0: the library's default, 64 Mbases = 16 MB) with an event behind
+ * The codes cross PCIe in pieces of piece_bases positions (0: the library's default, 256 Mbases = 64 MB) with an event behind
  * each: frisk_seq_commit does not wait for them, and frisk_profile_add(-1, -1) on the committed batch counts piece i while
  * piece i + 1 is on its way, so that of phase A only the last piece's kernel follows the upload.  Any other use of the batch
  * waits (on the device) for the last piece.  Replaces, with frisk_pack_2bit, the hand-off of scaffold strings from iterFasta

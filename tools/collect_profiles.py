@@ -35,7 +35,7 @@ if os.path.exists(mc) and os.path.exists(uk):
     if len(scans) >= 2 and big:
         lo = scans[-2][1]
         t0 = min(int(r["Start_Timestamp"]) for r in big if int(r["Start_Timestamp"]) > lo)
-        ev = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, "H2D copy (copy stream; the big ones: 16 MB pieces of the 2-bit codes)")
+        ev = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, "H2D copy (copy stream; the big ones: 64 MB pieces of the 2-bit codes)")
               for r in copies if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 20000]
         ev += [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Kernel_Name"].split("(")[0][:60]) for r in kern
                if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 20000]
@@ -43,7 +43,7 @@ if os.path.exists(mc) and os.path.exists(uk):
         under = sum(1 for a, b, w in ev if w.startswith("void profile_add") or w.startswith("profile_add"))
         with open(os.path.join(dst, name + "_stream_overlap.txt"), "w") as fh:
             fh.write("# rocprofv3 --kernel-trace --memory-copy-trace -- python3 tools/stream_job.py 3   (one whole C5-shaped job, 0.25 B/base form)\n"
-                     "# the LAST job of the run, every event >= 0.02 ms, t = 0 at its first big H2D copy: the codes cross PCIe in 16 MB pieces\n"
+                     "# the LAST job of the run, every event >= 0.02 ms, t = 0 at its first big H2D copy: the codes cross PCIe in 64 MB pieces\n"
                      "# (copy stream) while one profile_add_kernel per piece runs on the compute stream behind its piece's event; only the\n"
                      "# last piece's kernel, finalize and the scan follow the upload.  %d profile_add launches in this job.\n"
                      "#   start [ms]   duration [ms]   what\n" % under)
