@@ -1270,6 +1270,32 @@ static int profile_add_range(frisk_ctx* c, int mask_host, int64_t p0, int64_t p1
         if (last) { HIPC(c, hipEventRecord(c->evp1, c->stream)); c->ms_pending[1] = true; }
         return FRISK_OK;
     }
+    // K = 8, a long range (a whole resident genome): 16-bit counters, ONE walk over the sequence (profile_add16_kernel; a wrapped
+    // counter sends its workgroup to the two-half form).  The walk halves, the flush doubles (65 536 fields per workgroup instead of
+    // 32 768 bins): measured 2.42 -> 1.33 ms on the 3.29 Gb shape, 0.345 -> 0.55 ms on the 410 Mb shard (tools/exp/prof_ab.py) - so from
+    // 2^30 positions per launch on.  (mask_host bit 1 = FRISK_PROFILE_ONE_PASS forces it: the tests' way to the overflow path.)
+#ifndef FRISK_PROF16
+#define FRISK_PROF16 1
+#endif
+    const bool one_pass = c->kmax == 8 && FRISK_PROF16 && ((mask_host & 2) || p1 - p0 >= (int64_t(1) << 30));
+    mask_host &= 1;
+    if (one_pass) {
+        const int64_t span16 = p1 - p0;
+        const int64_t nwords16 = span16 > 0 ? ((p1 + 31) >> 5) - (p0 >> 5) : 0;
+        int64_t nch = std::min<int64_t>(std::max<int64_t>(1, span16 / 65536), int64_t(c->num_cu));
+        const int64_t chunk_len16 = (nwords16 + nch - 1) / std::max<int64_t>(nch, 1);
+        nch = chunk_len16 > 0 ? (nwords16 + chunk_len16 - 1) / chunk_len16 : 0;
+        if (first) HIPC(c, hipEventRecord(c->evp0, c->stream));
+        if (span16 > 0) {
+            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(profile_add16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            profile_add16_kernel<<<int(nch), FRISK_PROF_NT, 131072, c->stream>>>(c->b().d_codes.p, c->b().d_inv.p, c->b().d_low.p, p0, p1, c->kmin,
+                                                                                 mask_host ? 1 : 0, int(c->nprof), chunk_len16,
+                                                                                 reinterpret_cast<unsigned long long*>(c->d_raw.p));
+        }
+        HIPC(c, hipGetLastError());
+        if (last) { HIPC(c, hipEventRecord(c->evp1, c->stream)); c->ms_pending[1] = true; }
+        return FRISK_OK;
+    }
     // order-K table privatised in LDS (u32): split in two halves at K = 8 (256 KiB does not fit a CU)
     const int halves = (c->kmax == 8) ? 2 : 1;
     const size_t lds = (size_t(1) << (2 * c->kmax)) / size_t(halves) * 4;

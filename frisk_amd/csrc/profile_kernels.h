@@ -190,6 +190,126 @@ __global__ __launch_bounds__(FRISK_PROF_NT) void profile_add_kernel(const uint32
     }
 }
 
+// K = 8 in ONE pass (round 4): the order-8 table as 4^8 SIXTEEN-bit counters, two to a word = 128 KiB, so that a workgroup
+// counts every max-mer of its chunk in one walk instead of making the walk once per half of the k-mer space (the walk - masks,
+// run flags, code extraction: ~10 instructions per position - is what the kernel's time is; the two-half form did it twice).
+// A 16-bit field can wrap (65 536 copies of one 8-mer inside one workgroup's chunk: a megabase of poly-A), and a wrap is
+// found the way the scan kernels find theirs: the table's grand total must equal the number of max-mer positions the
+// workgroup counted.  It never does in assemblies; where it does, the workgroup throws its table away and counts its chunk
+// again in the two-half form, one half after the other (32-bit counters in the same LDS).  Everything that does not go through
+// the table - short runs, the three scalars - is added to the global tables during the first walk only.
+__global__ __launch_bounds__(FRISK_PROF_NT) void profile_add16_kernel(const uint32_t* __restrict__ codes,
+                                                                       const uint32_t* __restrict__ inv,
+                                                                       const uint32_t* __restrict__ low, int64_t p0, int64_t p1,
+                                                                       int kmin, int mask_host, int nprof, int64_t chunk_words,
+                                                                       unsigned long long* __restrict__ raw) {
+    constexpr int K = 8;
+    constexpr uint32_t NW = (1u << (2 * K)) / 2;                            // 32 768 words: two 16-bit counters each, or one half's 32-bit counters
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    __shared__ unsigned long long red[2];                                   // max-mer positions counted / the table's grand total
+    const int64_t chunk = int64_t(blockIdx.x);
+    auto clear = [&]() {
+        for (uint32_t b = threadIdx.x; b < NW / 4; b += blockDim.x) reinterpret_cast<uint4*>(hist)[b] = make_uint4(0, 0, 0, 0);
+    };
+    clear();
+    if (threadIdx.x < 2) red[threadIdx.x] = 0ull;
+    __syncthreads();
+    const int64_t w_first = p0 >> 5, w_end = (p1 + 31) >> 5;               // bitmap words that hold [p0, p1)
+    const int64_t wb = w_first + chunk * chunk_words;
+    int64_t we = wb + chunk_words;
+    if (we > w_end) we = w_end;
+    const int64_t offK = table_offset(kmin, K);
+    auto topbits = [](int64_t k) -> uint32_t {
+        k = k < 0 ? 0 : (k > 32 ? 32 : k);
+        return uint32_t(0xFFFFFFFF00000000ull >> k);
+    };
+    // one walk over the chunk.  MODE 0: every max-mer into its 16-bit field, and everything that bypasses the table; MODE 1 / 2: the
+    // max-mers of half 0 / 1 into 32-bit counters, nothing else
+    auto walk = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        unsigned long long tot = 0, kpos = 0, nn = 0, mine = 0;
+        for (int64_t wq = wb + threadIdx.x; wq < we; wq += blockDim.x) {
+            const int64_t base = wq << 5;
+            const uint32_t i0 = inv[wq], i1 = inv[wq + 1], l0 = low[wq], l1 = low[wq + 1];
+            const uint32_t c0 = codes[2 * wq], c1 = codes[2 * wq + 1], c2 = codes[2 * wq + 2];
+            const uint32_t inr = topbits(p1 - base) & ~topbits(p0 - base);
+            const uint32_t e0 = i0 | (mask_host ? l0 : 0u), e1 = i1 | (mask_host ? l1 : 0u);
+            const uint64_t V = ~((uint64_t(e0) << 32) | e1);
+            uint64_t F = V;
+            F &= F << 1; F &= F << 2; F &= F << 4;                          // eight countable bases in a row
+            const uint32_t fullm = uint32_t(F >> 32) & inr;
+            const uint64_t lo64 = (uint64_t(c0) << 32) | c1, hi64 = (uint64_t(c1) << 32) | c2;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (fullm & (0x80000000u >> j)) {
+                    const uint32_t code = uint32_t((j < 16 ? lo64 : hi64) >> (48 - 2 * (j & 15))) & 0xFFFFu;
+                    if (MODE == 0) atomicAdd(&hist[code >> 1], 1u << ((code & 1u) * 16u));
+                    else if ((code >> 15) == uint32_t(MODE - 1)) atomicAdd(&hist[code & (NW - 1u)], 1u);
+                }
+            }
+            if (MODE == 0) {
+                mine += uint32_t(__popc(fullm));
+                uint32_t shortm = uint32_t(V >> 32) & ~uint32_t(F >> 32) & inr;
+                while (shortm) {
+                    const int j = __clz(int(shortm));
+                    shortm &= ~(0x80000000u >> j);
+                    const int run = __clzll((long long)(~(V << j)));        // < 8 here
+                    if (run >= kmin) {
+                        const uint32_t c16 = uint32_t((j < 16 ? lo64 : hi64) >> (48 - 2 * (j & 15))) & 0xFFFFu;
+                        atomicAdd(&raw[table_offset(kmin, run) + (c16 >> (16 - 2 * run))], 1ull);
+                    }
+                }
+                const uint64_t NP = ~((uint64_t(i0 & l0) << 32) | (i1 & l1));   // not a PAD
+                uint64_t G = NP;
+                G &= G << 1; G &= G << 2; G &= G << 4;                      // a K-mer can start here (L329): no PAD in reach
+                const uint32_t real = uint32_t(NP >> 32) & inr;
+                tot += __popc(real);
+                nn += __popc(real & (i0 | l0));                             // not an uppercase A/T/G/C (countN, L106-118)
+                kpos += __popc(uint32_t(G >> 32) & inr);
+            }
+        }
+        if (MODE == 0) {
+            for (int o = 32; o > 0; o >>= 1) {
+                tot += __shfl_down(tot, o); kpos += __shfl_down(kpos, o); nn += __shfl_down(nn, o); mine += __shfl_down(mine, o);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                if (tot) atomicAdd(&raw[nprof + 0], tot);
+                if (kpos) atomicAdd(&raw[nprof + 1], kpos);
+                if (nn) atomicAdd(&raw[nprof + 2], nn);
+                if (mine) atomicAdd(&red[0], mine);
+            }
+        }
+    };
+    walk(std::integral_constant<int, 0>{});
+    __syncthreads();
+    {   // the table's grand total
+        unsigned long long sum = 0;
+        for (uint32_t b = threadIdx.x; b < NW; b += blockDim.x) { const uint32_t v = hist[b]; sum += (v & 0xFFFFu) + (v >> 16); }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&red[1], sum);
+    }
+    __syncthreads();
+    if (red[0] == red[1]) {                 // (uniform) no field wrapped: every counter is what it says
+        for (uint32_t b = threadIdx.x; b < NW; b += blockDim.x) {
+            const uint32_t v = hist[b];
+            if (v & 0xFFFFu) atomicAdd(&raw[offK + 2u * b], (unsigned long long)(v & 0xFFFFu));
+            if (v >> 16) atomicAdd(&raw[offK + 2u * b + 1u], (unsigned long long)(v >> 16));
+        }
+        return;
+    }
+    for (int half = 0; half < 2; ++half) {  // a wrapped field: the chunk again, half by half, in 32-bit counters
+        __syncthreads();
+        clear();
+        __syncthreads();
+        if (half == 0) walk(std::integral_constant<int, 1>{}); else walk(std::integral_constant<int, 2>{});
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < NW; b += blockDim.x) {
+            const uint32_t v = hist[b];
+            if (v) atomicAdd(&raw[offK + uint32_t(half) * NW + b], (unsigned long long)v);
+        }
+    }
+}
+
 // The same counting for kmax > 8 (4^K 32-bit counters no longer fit a CU's LDS): every position's ONE update goes straight to
 // the global table of its order.  A lane owns one 32-position word of the bitmaps as above; 24-bit codes (12 bases).
 // ~20 ms per 400 Mb - the reference's -k is unbounded (L1197-1206) but its own cost grows with 4^K; this path is for

@@ -302,8 +302,9 @@ class Engine:
     def profile_reset(self):
         self._check(self._lib.frisk_profile_reset(self._ctx))
 
-    def profile_add(self, mask_host=False, pos_begin=-1, pos_end=-1):
-        self._check(self._lib.frisk_profile_add(self._ctx, 1 if mask_host else 0, pos_begin, pos_end))
+    def profile_add(self, mask_host=False, pos_begin=-1, pos_end=-1, one_pass=False):
+        """one_pass=True (test hook, kmax = 8): the 16-bit one-pass form that long ranges take by themselves, on any size."""
+        self._check(self._lib.frisk_profile_add(self._ctx, (1 if mask_host else 0) | (2 if one_pass else 0), pos_begin, pos_end))
 
     def profile_raw(self):
         out = np.empty(self.nprof + 4, dtype=np.int64)

@@ -177,7 +177,10 @@ int frisk_seq_read(frisk_ctx* ctx, int32_t seq_index, int64_t offset, int64_t n,
  * -> finalize (adds the reverse complement, L350-351, and builds the genome-side IVOM table). */
 int frisk_profile_reset(frisk_ctx* ctx);
 /* Count the k-mers that START in padded positions [pos_begin,pos_end) of the resident batch;
- * pos_begin = pos_end = -1 means the whole batch.  mask_host: --maskHost (L336-337). */
+ * pos_begin = pos_end = -1 means the whole batch.  mask_host: bit 0 = --maskHost (L336-337); bit 1 = FRISK_PROFILE_ONE_PASS, a test
+ * hook: at kmax = 8 take the one-pass form with 16-bit LDS counters (what ranges of 2^30+ positions take by themselves; a wrapped
+ * counter falls back to the two-pass form) whatever the size.  Same counts either way. */
+#define FRISK_PROFILE_ONE_PASS 2
 int frisk_profile_add(frisk_ctx* ctx, int mask_host, int64_t pos_begin, int64_t pos_end);
 int64_t frisk_seq_padded_len(const frisk_ctx* ctx);
 /* Raw (linear, summable) profile state: int64[frisk_profile_raw_len()] on the device.  To

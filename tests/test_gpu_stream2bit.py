@@ -139,3 +139,32 @@ def test_dense_masks_and_bad_runs():
         with pytest.raises(_ffi.FriskHipError):
             e.stage_2bit(codes, np.array([[0, P + 1]]), rl, lens)
         same(run(e), ref)                                    # a refused stage leaves the resident batch alone
+
+
+def test_one_pass_profile_counter_overflow_falls_back():
+    """Phase A at K = 8 over a long range (2^30+ positions; here forced: one_pass=True) counts in 16-bit LDS fields, one pass
+    (profile_add16_kernel); 65 536+ copies of one 8-mer inside one workgroup's chunk wrap a field - found by the table's grand total, and the workgroup counts its chunk again in the two-half
+    32-bit form.  A scaffold with a 200 kb poly-A stretch, a 150 kb (CA)n and a 100 kb (AAT)n between random sequence: the
+    profile must be the oracle's to the last count, with and without --maskHost, whole and in position ranges."""
+    from oracle import frisk_oracle_np as N
+    from frisk_amd import Engine
+    rng = np.random.default_rng(21)
+    rnd = lambda n: rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes()      # noqa: E731
+    s0 = rnd(50_000) + b"A" * 200_000 + rnd(30_000) + b"CA" * 75_000 + b"N" * 50 + b"aat" * 33_000 + rnd(70_000)
+    s1 = rnd(40_000) + b"T" * 140_000
+    seqs = [s0, s1]
+    with Engine(1, 8) as e:
+        e.load(seqs)
+        for mask_host in (False, True):
+            osym, ometa = N.genome_profile(seqs, 1, 8, mask_host=mask_host)
+            for one_pass in (True, False):
+                e.profile_reset(); e.profile_add(mask_host=mask_host, one_pass=one_pass); e.profile_finalize()
+                sym, tl, ex, nn = e.profile_get()
+                assert np.array_equal(sym, osym) and (tl, ex, nn) == tuple(ometa), (mask_host, one_pass)
+        P = e.padded_len
+        e.profile_reset()
+        for a, b in ((0, 100_032), (100_032, 400_000), (400_000, P)):
+            e.profile_add(pos_begin=a, pos_end=b, one_pass=True)
+        e.profile_finalize()
+        osym, ometa = N.genome_profile(seqs, 1, 8)
+        assert np.array_equal(e.profile_get()[0], osym)
