@@ -73,6 +73,12 @@ out = {
         "wave_issue_stall_frac": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
         "lds_bank_conflict_frac_of_lds_cycles": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
         "lds_active_quadcycles_per_window": c["SQ_LDS_IDX_ACTIVE"] / n_win,
+        # scratch traffic, by counter: vector-memory instructions per window against what the hot path's ISA holds per window (four
+        # waves: ~8 vectorised sequence loads in stage 1 + 20 ring loads each; stores: the parking wave's 20, a fresh window's 80 one
+        # time in 16, the row's 6) - spilled registers reloaded at run time would come on top of these
+        "vmem_rd_instr_per_window": c["SQ_INSTS_VMEM_RD"] / n_win if "SQ_INSTS_VMEM_RD" in c else None,
+        "vmem_wr_instr_per_window": c["SQ_INSTS_VMEM_WR"] / n_win if "SQ_INSTS_VMEM_WR" in c else None,
+        "vmem_instr_expected_from_hot_isa_per_window": {"rd": 4 * (8 + 20), "wr": 20 + 80 / 16.0 + 6},
         "fp64_lane_ops_per_s": fp64_lane_ops,
         "fp64_lane_ops_peak_per_s": 78.6e12 / 2.0,       # 78.6 TFLOP/s vector FP64 = 39.3 T fused multiply-add lanes per second
         "fp64_frac_of_vector_peak": fp64_lane_ops / (78.6e12 / 2.0),
