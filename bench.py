@@ -143,6 +143,8 @@ def inclusive_block(eng, lens, step, fence, steps, rows, bases):
     phase A: the codes cross PCIe in pieces and profile_add follows the pieces.  Every timed job is cold: a fresh batch in the
     other slot, the adaptive counter width sampled again.  Host buffers page-locked.  Three forms of the same job:
       from_2bit    0.25 B/base codes + run lists of the two masks (frisk_pack_2bit -> frisk_seq_stage_2bit)   <- the figure
+      stream_of_jobs_2bit  the same for job after job: the NEXT job's upload runs under this job's scan (two batch slots), every
+                   job still cold - what a queue of assemblies, or of query chunks against one host profile, gets
       from_packed  0.5 B/base: codes + two dense bitmaps (frisk_seq_stage_packed)
       from_ascii   1 B/base, packed on the device (frisk_seq_stage)"""
     import numpy as np
@@ -182,7 +184,11 @@ def inclusive_block(eng, lens, step, fence, steps, rows, bases):
     def job_ascii():
         eng.stage(views); eng.commit(); step()
 
+    def stream_2bit():                   # a STREAM of jobs: the next assembly's upload under this one's scan (commit = device-side wait)
+        eng.stage_2bit(codes2, inv_runs, low_runs, lens); step(); eng.commit()
+
     timed(job_2bit, "from_2bit", codes2.nbytes + inv_runs.nbytes + low_runs.nbytes, steps)
+    timed(stream_2bit, "stream_of_jobs_2bit", codes2.nbytes + inv_runs.nbytes + low_runs.nbytes, steps)
     timed(job_packed, "from_packed", codes.nbytes + inv.nbytes + low.nbytes, max(2, steps // 2))
     timed(job_ascii, "from_ascii", total, max(2, steps // 2))
     out["value"] = out["from_2bit"]["windows_per_s"]
