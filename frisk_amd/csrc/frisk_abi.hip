@@ -1701,10 +1701,15 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         int64_t chunk_cap = can_slide ? 16 : 8;
         if (can_slide && FRISK8_CHUNK_LONG > 16) chunk_cap = std::max<int64_t>(16, std::min<int64_t>(FRISK8_CHUNK_LONG, n / (int64_t(c->num_cu) * 3 * 64)));
         int64_t chunk8 = std::max<int64_t>(1, std::min<int64_t>(n / (int64_t(c->num_cu) * 3 * 8), chunk_cap));
-        // (2 048 .. 12 287 windows - BASELINE's C3, a rank's share of a small genome - in chunks of two: every second window slides and reads
-        //  the ring.  Measured on C3, 12 063 windows: window by window 310 us, chunks of 2: 279, of 8: 277, of 16 - one round of the
-        //  launch's workgroups, all in step - 384; 6 000 windows: 165 / 152 / 224 / 309 - tools/exp/c3_sweep.py)
-        if (can_slide && chunk8 < 2 && n >= 2048) chunk8 = 2;
+        // A SHORT scan (fewer than 2 x 16 windows per workgroup: BASELINE's C3, a rank's share of a small genome) is dealt statically in
+        // TWO rounds of the launch's workgroups: chunks of ceil(n / (2 x workgroups)) windows, tables sliding and the ring inside a chunk.
+        // Measured (tools/exp/c3_sweep.py, us per scan of the first n windows of the shard; window by window / the best chunk):
+        // 1 500: 55 / 55 (1);  3 000: 87 / 86 (2);  6 000: 160 / 137 (4);  12 063: 303 / 243 (8);  24 000: 550 / 451 (16) - one round
+        // of longer chunks puts every workgroup through the same stage at the same time (12 063 in chunks of 16: 323), chunks dealt by
+        // counters cost such a scan an atomic's round trip per chunk (12 063 in chunks of 8: 269 dealt, 243 static).
+        const int64_t wgs3 = int64_t(c->num_cu) * (narrow8 ? 3 : FRISK_K7_WPS);
+        const bool short_scan = can_slide && n < wgs3 * 2 * 16 && !(flags & FRISK_SCAN_CHUNKS) && !tune_env("FRISK_SCAN_CHUNK");
+        if (short_scan) chunk8 = std::max<int64_t>(1, (n + wgs3 * 2 - 1) / (wgs3 * 2));
         if (flags & FRISK_SCAN_CHUNKS) chunk8 = 8;
         if (const char* ev = tune_env("FRISK_SCAN_CHUNK")) chunk8 = std::max<int64_t>(1, std::atoll(ev));
         // inside a chunk the order-K table slides from window to window where two windows share more than half their bases
@@ -1729,7 +1734,7 @@ static int scan_impl(frisk_ctx* c, int32_t w, int32_t inc, uint32_t flags, int64
         //  ... and no more chunks than the launch has workgroups - one round: a second chunk for a few of them doubled its time)
         if (nchunks >= 64 * 32) P.sel_mod = int32_t(std::max<int64_t>(32, (nchunks + int64_t(c->num_cu) * 3 - 1) / (int64_t(c->num_cu) * 3)));
         // chunks dealt by counters (scan8_kernel.h) where a chunk is long enough to pay for the exchange: a short scan keeps the static deal
-        const bool dealt = chunk8 >= 4;
+        const bool dealt = chunk8 >= 4 && !short_scan && !tune_env("FRISK_NO_DEAL");
         int bulk = (width == 4 && narrow8) ? 4 : 8;
         bool side = false;              // 4-bit bulk with the side table (scan8_kernel.h, SIDE)
         const bool side_ok = narrow8 && !debug;
