@@ -2,6 +2,9 @@
 """Extended differential fuzz of the scan kernels against the compiled C oracle (GPU box): like tests/test_gpu_fuzz.py but
 biased towards what round 2 added - K = 6..8 with kmin <= K-3, windows <= 5120, low-complexity runs that wrap 4- and 8-bit
 counters, many short invalid runs (orphan-list overflow), rescued small scaffolds longer than the kernel's reach, tiles.
+FUZZ_R4=1 (round 4): the batch goes up in the 2-bit + run-list form in small pieces (stage_2bit, the profile following the
+pieces), the profile takes the one-pass 16-bit kernel on every third seed, and every second seed scans with the job's own
+schedule (no forced chunks: the device-side width verdict, the short-scan rounds and the packed row block decide).
 usage: fuzz_long.py <first seed> <n seeds> [minutes]"""
 import os, sys, time
 import numpy as np
@@ -54,14 +57,21 @@ for seed in range(seed0, seed0 + nseeds):
     all_ = bool(rng.integers(0, 2))
     rip = bool(rng.integers(0, 2)) and kmin <= 2
     tag = "seed %d k=%d..%d w=%d i=%d all=%s lens=%s" % (seed, kmin, kmax, w, inc, all_, [len(x) for x in seqs])
+    r4 = os.environ.get("FUZZ_R4") == "1"
     with Engine(kmin, kmax) as e:
-        e.load(seqs)
-        e.profile_reset(); e.profile_add(); e.profile_finalize()
+        if r4:
+            codes, ir, lr, lens = e.pack_2bit(seqs, pinned=bool(seed & 4))
+            e.stage_2bit(codes, ir, lr, lens, piece_bases=int(rng.choice([0, 1024, 4096, 1 << 16])))
+            e.commit()
+            e.profile_reset(); e.profile_add(one_pass=seed % 3 == 0); e.profile_finalize()
+        else:
+            e.load(seqs)
+            e.profile_reset(); e.profile_add(); e.profile_finalize()
         sym, tl, ex, nn = e.profile_get()
         # (round 3: the schedule of a long scan - chunks, sliding tables, the ring - on every case; 4-bit counters first on odd seeds)
         # (4-bit counters with the side table for period-4 max-mers on seeds = 3 mod 4; the rows must then equal the default scan's bit for bit)
         side = (seed & 3) == 3 and kmax == 8
-        res = e.scan(w, inc, rip=rip, scaffolds_all=all_, chunks=True, bits4=bool(seed & 1) and kmax == 8 and not side, side4=side)
+        res = e.scan(w, inc, rip=rip, scaffolds_all=all_, chunks=not (r4 and seed & 2), bits4=bool(seed & 1) and kmax == 8 and not side, side4=side)
         stat = e.scan_stat() + (e.scan_side(),)
         sided += e.scan_side(); handed_side += stat[1] if e.scan_side() else 0
         if side:
