@@ -211,13 +211,21 @@ def _main(argv=None):
     sharded = world > 1 or os.environ.get("FRISK_FORCE_SHARDED") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FRISK_DIST_REHEARSAL=1: the N-rank job on ONE GPU - every rank on device 0, gloo instead of RCCL (which refuses two ranks
+    # on one device): a functional rehearsal of the sharded path (tiles, all-reduce, row gather) where only one GPU exists
+    rehearsal = os.environ.get("FRISK_DIST_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if sharded and not dist.is_initialized():
         import torch
         torch.cuda.set_device(local_rank)
         if world == 1:      # FRISK_FORCE_SHARDED outside a launcher: a one-rank rendezvous of our own
             for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(key, val)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         print("frisk --", pp.FRISK_VERSION)
     genomepickle = makePicklePath(args, "genome")
