@@ -102,3 +102,35 @@ for path in [fa] + ([gz] if os.path.exists(gz) else []):
         digest = hashlib.sha256(open(os.path.join(tmp, "raw_window_scores.bed"), "rb").read()).hexdigest()[:16] if out.returncode == 0 else None
         print(json.dumps({"run": os.path.basename(path), "label": label, "rc": out.returncode, "wall_s": round(wall, 2), "rows": rows, "table_sha256_16": digest,
                           "split": split, "err": out.stderr[-300:] if out.returncode else None}), flush=True)
+
+# E2E_RANKS=N: the same job as N real ranks under torchrun on THIS one GPU (FRISK_DIST_REHEARSAL=1: gloo in RCCL's place) - a
+# functional run of the sharded path at full size (tiles per rank, all-reduce, 3 M rows gathered on rank 0); its table must carry
+# the digest of the one-process table above.  First run parses (and leaves the seek index), the second reads tiles through it.
+if os.environ.get("E2E_RANKS"):
+    import hashlib
+    nr = int(os.environ["E2E_RANKS"])
+    tmp = os.path.join(work, "R%d_" % nr + os.path.basename(fa))
+    for label, extra in (("%d ranks on one GPU (rehearsal), cold caches" % nr, ["--recalc", "--recalcWin"]),
+                         ("%d ranks on one GPU (rehearsal), seek index, profile recomputed" % nr, ["--recalcWin"])):
+        if "seek index" in label:
+            for f in os.listdir(tmp):
+                if f.endswith("_genome.p"):
+                    os.remove(os.path.join(tmp, f))          # (so that phase A runs again, through the index this time)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nr), "--master-addr", "127.0.0.1",
+               "--master-port", "29731", "-m", "frisk_amd", "-H", fa, "-k", "8", "-w", "5000", "-i", "1000", "-t", tmp,
+               "--exitAfter", "WindowKLD"] + extra
+        env = dict(os.environ, FRISK_TIMING="1", FRISK_DIST_REHEARSAL="1", PYTHONPATH=ROOT)
+        t0 = time.time()
+        out = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+        wall = time.time() - t0
+        split = None
+        for line in out.stderr.splitlines():
+            if line.startswith('{"frisk_timing"'):
+                split = json.loads(line)
+        tab = os.path.join(tmp, "raw_window_scores.bed")
+        ok = out.returncode == 0 and os.path.exists(tab)
+        print(json.dumps({"run": os.path.basename(fa), "label": label, "rc": out.returncode, "wall_s": round(wall, 2),
+                          "rows": sum(1 for _ in open(tab)) - 1 if ok else -1,
+                          "table_sha256_16": hashlib.sha256(open(tab, "rb").read()).hexdigest()[:16] if ok else None,
+                          "split_rank0": split, "index_used": "through the index" in out.stderr,
+                          "err": out.stderr[-600:] if out.returncode else None}), flush=True)
