@@ -160,3 +160,51 @@ def test_long_handover_lists_of_satellite_arrays():
             part = e.scan(5000, 1000, rip=True, bits4=True, c0=c0, c1=min(n, c0 + step))
             for f in ("start", "stop", "status", "kld", "gc", "pi", "si", "cri"):
                 assert np.array_equal(getattr(part, f), getattr(res, f)[c0:c0 + step], equal_nan=True), (f, c0)
+
+
+@pytest.mark.parametrize("factor", [0.4994, 0.5, 0.55, 0.6])
+def test_increments_around_half_a_window(factor):
+    """Increments from just below half a window (the last geometry whose tables slide) to 0.6 w (the CLI's default -i 2500 at w = 5000:
+    every window counted afresh, in chunks): same bits as the window-by-window scan, in every bulk form, on a sub-range, and the
+    oracle's rows."""
+    rng = np.random.default_rng(int(factor * 10000))
+    checked = 0
+    for case_no in range(6):
+        c = _case(rng)
+        c["kmax"] = 8
+        c["kmin"] = int(rng.integers(1, 6))
+        c["rip"] = c["rip"] and c["kmin"] <= 2
+        c["w"] = int(rng.choice([2000, 5000, 5120, 3001]))
+        c["inc"] = int(c["w"] * factor)
+        seqs = []
+        for q in range(int(rng.integers(1, 4))):
+            n = int(rng.choice([c["w"] + c["inc"], 9 * c["inc"] + c["w"] + 11, 40 * c["inc"] + 17]))
+            s = rng.choice(np.frombuffer(b"ATGC", dtype=np.uint8), size=n, p=rng.dirichlet([2, 2, 2, 2]))
+            for _ in range(int(rng.integers(0, 6))):
+                a = int(rng.integers(0, n))
+                ln = int(rng.choice([1, 8, 40, c["inc"] // 2, c["w"] // 3]))
+                if rng.integers(0, 2):
+                    s[a:a + ln] = ord("N")
+                else:
+                    s[a:a + ln] = np.resize(np.frombuffer(b"CA", dtype=np.uint8), len(s[a:a + ln]))
+            seqs.append(s.tobytes())
+        c["seqs"] = seqs
+        tag = "factor %s case %d: k=%d..8 w=%d i=%d all=%s lens=%s" % (factor, case_no, c["kmin"], c["w"], c["inc"], c["scaffolds_all"],
+                                                                       [len(s) for s in seqs])
+        with Engine(c["kmin"], 8) as e:
+            e.load(seqs)
+            e.profile_reset(); e.profile_add(); e.profile_finalize()
+            fresh = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"])
+            for kw in (dict(), dict(bits4=True), dict(side4=True)):
+                got = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"], chunks=True, **kw)
+                _same_bits(fresh, got, c["rip"], tag + " " + str(kw))
+            n = len(fresh)
+            if n > 12:
+                c0 = int(rng.integers(1, 8))
+                part = e.scan(c["w"], c["inc"], rip=c["rip"], scaffolds_all=c["scaffolds_all"], c0=c0, c1=n - 1, chunks=True, bits4=True)
+                for col in COLS:
+                    x, y = getattr(part, col), getattr(fresh, col)[c0:n - 1]
+                    assert np.array_equal(x.view(np.uint64 if x.dtype.itemsize == 8 else x.dtype),
+                                          y.view(np.uint64 if y.dtype.itemsize == 8 else y.dtype)), (tag, col, "range")
+            checked += _against_oracle(fresh, c, tag)
+    assert checked > 60
