@@ -165,8 +165,10 @@ inline bool read_index(const char* path, const MappedFile& f, std::vector<FaiEnt
         const int64_t full = r.len == 0 ? 0 : (r.len - 1) / r.linebases;                 // complete lines before the last
         const int64_t last = r.offset + full * r.linewidth + (r.len - full * r.linebases);  // byte behind the last base
         if (last > size) { why = "index entry beyond the end of the file: " + r.name; return false; }
-        if (f.base[r.offset - 1] != '\n') { why = "no line start where the index puts record " + r.name; return false; }
-        const char* he = f.base + r.offset - 1;                                          // the header line: back to its start
+        // (an empty record whose header is the file's last line and lacks the newline: build_index puts it at the end of the file)
+        const bool eof_header = r.len == 0 && r.offset == size && f.base[size - 1] != '\n';
+        if (!eof_header && f.base[r.offset - 1] != '\n') { why = "no line start where the index puts record " + r.name; return false; }
+        const char* he = f.base + r.offset - (eof_header ? 0 : 1);                       // the header line: back to its start
         const char* hb = he;
         while (hb > f.base && hb[-1] != '\n') --hb;
         const char* b = hb;

@@ -77,11 +77,69 @@ inline void track16(uint32_t m, int64_t p, int64_t& open, std::vector<int64_t>& 
     }
 }
 
+// one mask of 64 positions from p on, FIRST position in bit 63 (bit 63 - i = position p + i), into a run list with an open run carried along
+inline void track64_be(uint64_t m, int64_t p, int64_t& open, std::vector<int64_t>& out) {
+    if ((open < 0 && m == 0ull) || (open >= 0 && m == ~0ull)) return;      // nothing changes inside these 64: nearly always
+    bool on = open >= 0;
+    int pos = 0;
+    while (pos < 64) {
+        const uint64_t y = (on ? ~m : m) << pos;                           // the next position whose bit differs from the state
+        if (y == 0ull) break;
+        pos += __builtin_clzll(y);
+        if (!on) { open = p + pos; on = true; }
+        else { push_run(out, open, p + pos); open = -1; on = false; }
+    }
+}
+
+// Sixty-four letters per step where the host has AVX-512BW + BMI2 (every x86 server the MI355X ships in): the letters' order is
+// reversed inside the vector first, so that the byte masks come out with the FIRST letter in bit 63 - the order of the code
+// words and of track64_be -; validity is four byte compares of the case-folded letters, the two code planes are two bit tests
+// (classify8's arithmetic: (c >> 1) & 3 = A 0, C 1, T 2, G 3 -> high' = low, low' = low ^ high), and PDEP interleaves the planes
+// into the 2-bit codes, thirty-two letters per instruction.  Same words and runs as the 8-letter form (tests/test_pack2_cpu.py
+// runs both).  The device pass of the HIP compiler sees a stub: this is host code.
+#if (defined(__x86_64__) || defined(_M_X64)) && !defined(__HIP_DEVICE_COMPILE__) && !defined(FRISK_PACK_NO_AVX512)
+#define FRISK_PACK_AVX512 1
+}  // namespace frisk_pack2
+#include <immintrin.h>
+namespace frisk_pack2 {
+inline bool have_avx512() {
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("bmi2");
+    return ok;
+}
+// positions [p, p + 64 k) with p a multiple of 16 and as many whole steps as fit below p1; returns the new p (s advances alike)
+__attribute__((target("avx512f,avx512bw,bmi2"))) inline int64_t pack64_avx512(const uint8_t*& s, int64_t p, int64_t p1, uint32_t* codes,
+                                                                              int64_t& inv_b, int64_t& low_b, Runs& out) {
+    const __m512i rev_in_lane = _mm512_set_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                                0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const __m512i rev_lanes = _mm512_set_epi64(1, 0, 3, 2, 5, 4, 7, 6);
+    const __m512i fold_m = _mm512_set1_epi8(char(0xDF)), cA = _mm512_set1_epi8('A'), cC = _mm512_set1_epi8('C'), cG = _mm512_set1_epi8('G'),
+                  cT = _mm512_set1_epi8('T'), b02 = _mm512_set1_epi8(0x02), b04 = _mm512_set1_epi8(0x04), b20 = _mm512_set1_epi8(0x20);
+    for (; p + 64 <= p1; p += 64, s += 64) {
+        __m512i v = _mm512_loadu_si512(reinterpret_cast<const void*>(s));
+        v = _mm512_permutexvar_epi64(rev_lanes, _mm512_shuffle_epi8(v, rev_in_lane));           // byte 63 = the first letter
+        const __m512i f = _mm512_and_si512(v, fold_m);
+        const uint64_t valid = _mm512_cmpeq_epi8_mask(f, cA) | _mm512_cmpeq_epi8_mask(f, cC) | _mm512_cmpeq_epi8_mask(f, cG) | _mm512_cmpeq_epi8_mask(f, cT);
+        const uint64_t lo = _mm512_test_epi8_mask(f, b02), hi = _mm512_test_epi8_mask(f, b04);
+        const uint64_t H = lo & valid, L = (lo ^ hi) & valid;                                     // code planes, first letter in bit 63
+        const uint64_t w01 = _pdep_u64(H >> 32, 0xAAAAAAAAAAAAAAAAull) | _pdep_u64(L >> 32, 0x5555555555555555ull);
+        const uint64_t w23 = _pdep_u64(H & 0xFFFFFFFFull, 0xAAAAAAAAAAAAAAAAull) | _pdep_u64(L & 0xFFFFFFFFull, 0x5555555555555555ull);
+        uint32_t* c = codes + (p >> 4);
+        c[0] |= uint32_t(w01 >> 32); c[1] |= uint32_t(w01); c[2] |= uint32_t(w23 >> 32); c[3] |= uint32_t(w23);
+        track64_be(~valid, p, inv_b, out.inv);
+        track64_be(valid & _mm512_test_epi8_mask(v, b20), p, low_b, out.low);
+    }
+    return p;
+}
+#else
+inline bool have_avx512() { return false; }
+inline int64_t pack64_avx512(const uint8_t*&, int64_t p, int64_t, uint32_t*, int64_t&, int64_t&, Runs&) { return p; }
+#endif
+
 // positions [p0, p1) of one scaffold piece: `src` = its bytes, codes written to the words of `codes` (2 bits per position,
 // big-endian in the word; the caller zeroed them), runs appended.  Words shared by two pieces are written by ONE thread only
 // because the threads' ranges are cut at multiples of 32.  Whole 16-position words go eight letters at a time (classify8);
-// the ragged head and tail of a piece letter by letter.
-inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* codes, Runs& out) {
+// sixty-four where the host has AVX-512, `wide`), the ragged head and tail of a piece letter by letter.
+inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* codes, Runs& out, bool wide = true) {
     const uint8_t* T = lut().t;
     int64_t inv_b = -1, low_b = -1;
     int64_t p = p0;
@@ -102,6 +160,7 @@ inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* cod
         }
     };
     letters(std::min<int64_t>(p1, (p0 + 15) & ~int64_t(15)));              // up to the first word boundary
+    if (wide && have_avx512()) p = pack64_avx512(s, p, p1, codes, inv_b, low_b, out);
     for (; p + 16 <= p1; p += 16, s += 16) {
         uint64_t a, b;
         std::memcpy(&a, s, 8); std::memcpy(&b, s + 8, 8);
@@ -117,7 +176,7 @@ inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* cod
 
 // The whole batch: scaffold s at padded positions [off[s], off[s] + lens[s]).  `codes`: 2 * P / 32 words, zeroed here.
 // Work is cut at multiples of 32 positions and dealt to `threads` workers; runs that cross a cut are merged afterwards.
-inline void pack_batch(const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq, uint32_t* codes, Runs& out, int threads) {
+inline void pack_batch(const uint8_t* const* seqs, const int64_t* lens, int32_t n_seq, uint32_t* codes, Runs& out, int threads, bool wide = true) {
     const int64_t P = padded_len(lens, n_seq);
     std::vector<int64_t> off(size_t(n_seq) + 1, 0);
     for (int32_t s = 0; s < n_seq; ++s) off[size_t(s) + 1] = off[size_t(s)] + lens[s] + 1;
@@ -134,7 +193,7 @@ inline void pack_batch(const uint8_t* const* seqs, const int64_t* lens, int32_t 
         if (s < 0) s = 0;
         for (; s < n_seq && off[size_t(s)] < b; ++s) {
             const int64_t q0 = std::max<int64_t>(a, off[size_t(s)]), q1 = std::min<int64_t>(b, off[size_t(s)] + lens[s]);
-            if (q1 > q0) pack_piece(seqs[s] + (q0 - off[size_t(s)]), q0, q1, codes, part[size_t(t)]);
+            if (q1 > q0) pack_piece(seqs[s] + (q0 - off[size_t(s)]), q0, q1, codes, part[size_t(t)], wide);
         }
     };
     if (T == 1) work(0);

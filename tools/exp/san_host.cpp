@@ -37,7 +37,7 @@ int main() {
         const int64_t P = frisk_pack2::padded_len(lens.data(), n_seq);
         std::vector<uint32_t> codes(size_t(P / 16), 0xDEADBEEFu);
         frisk_pack2::Runs R;
-        frisk_pack2::pack_batch(ptr.data(), lens.data(), n_seq, codes.data(), R, 1 + int(rng() % 7));
+        frisk_pack2::pack_batch(ptr.data(), lens.data(), n_seq, codes.data(), R, 1 + int(rng() % 7), (round & 1) != 0);      // (odd rounds: the AVX-512 path where the host has it)
         // letter by letter
         std::vector<uint32_t> want(size_t(P / 16), 0u), inv(size_t(P / 32), 0u), low(size_t(P / 32), 0u);
         int64_t pos = 0;
@@ -117,15 +117,12 @@ int main() {
             CHECK(frisk_fasta::write_index(ip.c_str(), f, idx, why));
             std::vector<frisk_fasta::FaiEntry> back;
             const bool rd = frisk_fasta::read_index(ip.c_str(), f, back, why);
-            // (one known refusal, on the safe side: a header on the file's last line without a newline - an empty record at the end of
-            //  the file - is indexed but not accepted back: such a file is parsed every time)
-            const bool eof_header = !text.empty() && text.back() != '\n' && !idx.empty() && idx.back().len == 0 && idx.back().offset == int64_t(text.size());
-            if (!(rd && back.size() == idx.size()) && !eof_header) std::printf("read_index: %s (file of %zu bytes, %zu records)\n", why.c_str(), text.size(), idx.size());
-            CHECK((rd && back.size() == idx.size()) || eof_header);
+            if (!(rd && back.size() == idx.size())) std::printf("read_index: %s (file of %zu bytes, %zu records)\n", why.c_str(), text.size(), idx.size());
+            CHECK(rd && back.size() == idx.size());
             ::unlink(ip.c_str());
         }
         ::unlink(path.c_str());
     }
-    std::printf("%s (%d failed checks)\n", fails ? "FAILED" : "ok", fails);
+    std::printf("%s (%d failed checks; AVX-512 packer %s)\n", fails ? "FAILED" : "ok", fails, frisk_pack2::have_avx512() ? "exercised" : "not available on this host");
     return fails ? 1 : 0;
 }
