@@ -251,6 +251,14 @@ def _main(argv=None):
     clock.lap("startup (imports + HIP context)")
     table = None
     index_writers = []
+    out_threads, out_err = [], []           # the score table text and the window cache on their way to disk
+
+    def _join_outputs():
+        for th in out_threads:
+            th.join()
+        del out_threads[:]
+        if out_err:
+            raise out_err.pop(0)
 
     # Sharded jobs: a rank with a seek index of the FASTA (fasta_index.h; in --tempDir, or beside the file) copies the bytes of
     # its tiles instead of parsing all of it.  --recalc (store_false: recompute) ignores every index; where a rank had to
@@ -327,31 +335,34 @@ def _main(argv=None):
             except ZeroDivisionError as err:
                 zero, table = err, getattr(err, "table", None)
             clock.lap("phase B (scan)")
-            dumper, dump_err = None, []
             if rank == 0 and table is not None:
-                if zero is None:
-                    # the window cache (L1501) is pickled while the table text is formatted and written (native code, outside the
-                    # interpreter lock): two files of the same rows, neither reads the other
-                    import threading
+                import threading
 
-                    def _dump():
+                def _bg(fn, *a):
+                    def run():
                         try:
-                            _dump_window_cache(windowsPickle, table)
-                        except BaseException as err:        # noqa: B902 - re-raised on the main thread below
-                            dump_err.append(err)
-                    dumper = threading.Thread(target=_dump, name="frisk-window-cache")
-                    dumper.start()
-                # the reference writes and prints row by row (L1487-1494): what it had written before dying is written here too
-                try:
+                            fn(*a)
+                        except BaseException as err:        # noqa: B902 - re-raised on the main thread (_join_outputs)
+                            out_err.append(err)
+                    th = threading.Thread(target=run, name="frisk-" + fn.__name__)
+                    th.start()
+                    out_threads.append(th)
+                if zero is None:
+                    # Two files of the same rows - the window cache (L1501) and the table text (native formatter, outside the
+                    # interpreter lock), neither reads the other - written in the background while thresholds, segmentation and
+                    # features are computed from the same (read-only) columns; joined before this function returns or raises.
+                    _bg(_dump_window_cache, windowsPickle, table)
+                    _bg(write_table, os.path.join(args.tempDir, args.outfile), table)
+                else:
+                    # the reference writes and prints row by row (L1487-1494): what it had written before dying is written here too
                     write_table(os.path.join(args.tempDir, args.outfile), table)
-                finally:
-                    if dumper is not None:
-                        dumper.join()
-                clock.lap("score table text + window pickle")
+                clock.lap("score table text + window pickle started" if zero is None else "score table text")
             if zero is not None:
                 raise zero
-            if dump_err:
-                raise dump_err[0]
+    except BaseException:
+        for th in out_threads:
+            th.join()
+        raise
     finally:
         for th in index_writers:
             th.join()
@@ -359,55 +370,64 @@ def _main(argv=None):
     if rank != 0:
         return 0
     if args.exitAfter == "WindowKLD":
+        _join_outputs()
+        clock.lap("score table text + window pickle written")
         log.info("Finished calculating window KLD scores. Exiting.")
         clock.report()
         return 0
 
-    # ---- thresholds and features (L1522-1530, L1671-1707)
-    kld = np.where(table.kld_is_int0 != 0, 0.0, table.kld)
-    with np.errstate(divide="ignore"):
-        logKLD = np.log10(kld.reshape(-1, 1))
-    threshold, _bins = pp.setKLDThresh(args, logKLD)
-    threshold = float(np.ravel(threshold)[0])
-    log.info("log10(KLD) threshold = %s", threshold)
-    clock.lap("KLD threshold")
-    if args.hmmKLD:                                                     # L1537-1548
-        from .hmm import hmm2BED, hmmBED2GFF
-        intervals, _model = hmm2BED(table)
-        with open(os.path.join(args.tempDir, args.hmmOutfile), "w") as fh:
-            fh.writelines(hmmBED2GFF(intervals))
-        log.info("HMM segmentation: %s state features (fit: %s EM rounds, log-likelihood %s)", len(intervals),
-                 getattr(_model, "n_iter_", "?"), getattr(_model, "loglik_", "?"))
-        clock.lap("HMM segmentation + GFF")
-    if args.runProjection:                                              # L1556-1596: counts for the projection
-        from .fasta import readFasta
-        from .projection import symmetricCounts
-        feats, _ = pp.thresholdKLD(table, threshold, args, merge=(args.dimReduce == "features"))
-        names, seqs = readFasta(querySeq)
-        fasta = dict(zip(names, seqs))
-        labelled = [(":".join([f[0], str(f[1]), str(f[2])]), fasta[f[0]][int(f[1]) - 1:int(f[2])]) for f in feats if f[0] in fasta]
-        anomLabels, anomCounts = symmetricCounts(labelled, args.pcaMin, args.pcaMax, device=local_rank)
-        if args.dumpPCAdata:
-            with open(os.path.join(args.tempDir, "anomLabels"), "wb") as fh:
-                pickle.dump(anomLabels, fh, protocol=2)
-            with open(os.path.join(args.tempDir, "anomCounts"), "wb") as fh:
-                pickle.dump(anomCounts, fh, protocol=2)
-        log.info("Symmetric k-mer proportions of %s anomalous windows computed; the %s projection is not built here.",
-                 len(labelled), args.runProjection)
-    anomalies, _sel = pp.thresholdKLD(table, threshold, args, merge=True)
-    log.info("Detected %s features above KLD threshold.", len(anomalies))
-    if args.gffOutfile:
-        with open(os.path.join(args.tempDir, args.gffOutfile), "w") as fh:
-            for line in pp.anomaly2GFF(anomalies, args):
-                fh.write(line)
-    if rip:
-        feats = pp.thresholdRIP(table, args)
-        if feats:
-            with open(os.path.join(args.tempDir, args.RIPgff), "w") as fh:
-                for line in pp.RIP2GFF(feats):
+    try:
+        # ---- thresholds and features (L1522-1530, L1671-1707)
+        kld = np.where(table.kld_is_int0 != 0, 0.0, table.kld)
+        with np.errstate(divide="ignore"):
+            logKLD = np.log10(kld.reshape(-1, 1))
+        threshold, _bins = pp.setKLDThresh(args, logKLD)
+        threshold = float(np.ravel(threshold)[0])
+        log.info("log10(KLD) threshold = %s", threshold)
+        clock.lap("KLD threshold")
+        if args.hmmKLD:                                                     # L1537-1548
+            from .hmm import hmm2BED, hmmBED2GFF
+            intervals, _model = hmm2BED(table)
+            with open(os.path.join(args.tempDir, args.hmmOutfile), "w") as fh:
+                fh.writelines(hmmBED2GFF(intervals))
+            log.info("HMM segmentation: %s state features (fit: %s EM rounds, log-likelihood %s)", len(intervals),
+                     getattr(_model, "n_iter_", "?"), getattr(_model, "loglik_", "?"))
+            clock.lap("HMM segmentation + GFF")
+        if args.runProjection:                                              # L1556-1596: counts for the projection
+            from .fasta import readFasta
+            from .projection import symmetricCounts
+            feats, _ = pp.thresholdKLD(table, threshold, args, merge=(args.dimReduce == "features"))
+            names, seqs = readFasta(querySeq)
+            fasta = dict(zip(names, seqs))
+            labelled = [(":".join([f[0], str(f[1]), str(f[2])]), fasta[f[0]][int(f[1]) - 1:int(f[2])]) for f in feats if f[0] in fasta]
+            anomLabels, anomCounts = symmetricCounts(labelled, args.pcaMin, args.pcaMax, device=local_rank)
+            if args.dumpPCAdata:
+                with open(os.path.join(args.tempDir, "anomLabels"), "wb") as fh:
+                    pickle.dump(anomLabels, fh, protocol=2)
+                with open(os.path.join(args.tempDir, "anomCounts"), "wb") as fh:
+                    pickle.dump(anomCounts, fh, protocol=2)
+            log.info("Symmetric k-mer proportions of %s anomalous windows computed; the %s projection is not built here.",
+                     len(labelled), args.runProjection)
+        anomalies, _sel = pp.thresholdKLD(table, threshold, args, merge=True)
+        log.info("Detected %s features above KLD threshold.", len(anomalies))
+        if args.gffOutfile:
+            with open(os.path.join(args.tempDir, args.gffOutfile), "w") as fh:
+                for line in pp.anomaly2GFF(anomalies, args):
                     fh.write(line)
-        else:
-            log.info("No RIP features detected.")
+        if rip:
+            feats = pp.thresholdRIP(table, args)
+            if feats:
+                with open(os.path.join(args.tempDir, args.RIPgff), "w") as fh:
+                    for line in pp.RIP2GFF(feats):
+                        fh.write(line)
+            else:
+                log.info("No RIP features detected.")
+    except BaseException:
+        for th in out_threads:           # (the two output files are finished before the error travels on)
+            th.join()
+        raise
     clock.lap("anomaly / RIP features + GFF")
+    _join_outputs()
+    clock.lap("score table text + window pickle written")
     clock.report()
     return 0
