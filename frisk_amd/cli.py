@@ -260,6 +260,28 @@ def _main(argv=None):
         if out_err:
             raise out_err.pop(0)
 
+    def _bg(fn, *a):
+        import threading
+
+        def run():
+            try:
+                fn(*a)
+            except BaseException as err:        # noqa: B902 - re-raised on the main thread (_join_outputs)
+                out_err.append(err)
+        th = threading.Thread(target=run, name="frisk-" + fn.__name__)
+        th.start()
+        out_threads.append(th)
+
+    def _write_genome_pickle(arrays):
+        # the reference's pickled form (list of dicts + 3 metadata dicts, L356-359): 87 380 dict entries at K = 8, built and written
+        # beside the scan, which needs only the profile on the device
+        from .hotpath import profileToMaps
+        maps = profileToMaps(arrays[0], arrays[1], arrays[2], arrays[3], args.minWordSize, args.maxWordSize)
+        tmp = genomepickle + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as fh:
+            pickle.dump(maps, fh, protocol=2)
+        os.replace(tmp, genomepickle)
+
     # Sharded jobs: a rank with a seek index of the FASTA (fasta_index.h; in --tempDir, or beside the file) copies the bytes of
     # its tiles instead of parsing all of it.  --recalc (store_false: recompute) ignores every index; where a rank had to
     # parse, rank 0 writes the index beside the other caches for the next run - in the background, it is not needed by this one.
@@ -300,17 +322,17 @@ def _main(argv=None):
                 resident_names = D.profile_sharded(hp.engine, args.hostSeq, w, inc, mask_host=args.maskHost, scaffolds_all=all_,
                                                    index=_shard_index(args.hostSeq))
                 _note_shard_load(args.hostSeq)
-                genomeKmers = hp.profileMaps() if rank == 0 else None
+                profile_arrays = hp.engine.profile_get() if rank == 0 else None
             else:
                 hp._load(args.hostSeq)
                 clock.lap("packed sequence cache -> HBM" if hp.loaded_from_cache else "FASTA parse + upload + pack")
-                genomeKmers = hp.genomeProfile(args)
+                profile_arrays = hp.genomeProfileArrays(args)
             clock.lap("phase A (profile)" if not sharded else "phase A (parse + upload + profile + all-reduce)")
             if rank == 0:
-                with open(genomepickle, "wb") as fh:
-                    pickle.dump(genomeKmers, fh, protocol=2)
-                clock.lap("profile pickle")
+                _bg(_write_genome_pickle, profile_arrays)               # (joined with the other outputs, or right below)
             if args.exitAfter == "GenomeKmers":                          # L1443-1445: before any window is scored
+                _join_outputs()
+                clock.lap("profile pickle")
                 log.info("Finished counting kmers. Exiting.")
                 return 0
         # ---- phase B: window scores (L1454-1507)
@@ -336,17 +358,6 @@ def _main(argv=None):
                 zero, table = err, getattr(err, "table", None)
             clock.lap("phase B (scan)")
             if rank == 0 and table is not None:
-                import threading
-
-                def _bg(fn, *a):
-                    def run():
-                        try:
-                            fn(*a)
-                        except BaseException as err:        # noqa: B902 - re-raised on the main thread (_join_outputs)
-                            out_err.append(err)
-                    th = threading.Thread(target=run, name="frisk-" + fn.__name__)
-                    th.start()
-                    out_threads.append(th)
                 if zero is None:
                     # Two files of the same rows - the window cache (L1501) and the table text (native formatter, outside the
                     # interpreter lock), neither reads the other - written in the background while thresholds, segmentation and

@@ -233,6 +233,18 @@ class HotPath:
         sym, tl, ex, nn = e.profile_get()
         return profileToMaps(sym, tl, ex, nn, self.kMin, self.kMax)
 
+    def genomeProfileArrays(self, args, allreduce=False):
+        """genomeProfile() without the reference's dict form: the arrays of Engine.profile_get().  The CLI turns them into the
+        pickled form (profileToMaps) in the background - the scan needs only the profile on the device."""
+        self._load(args.hostSeq)
+        e = self.engine
+        e.profile_reset()
+        e.profile_add(mask_host=bool(getattr(args, "maskHost", False)))
+        if allreduce:
+            e.profile_allreduce()
+        e.profile_finalize()
+        return e.profile_get()
+
     def profileMaps(self):
         """The finished profile on the device in the reference's pickled form (list of dicts + 3 metadata dicts, L356-359)."""
         sym, tl, ex, nn = self.engine.profile_get()
