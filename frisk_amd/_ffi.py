@@ -35,6 +35,8 @@ SYMBOLS = [
     ("frisk_seq_set_names", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int32]),
     ("frisk_fasta_load", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32), _I64P]),
     ("frisk_fasta_digest", C.c_int, [C.c_char_p, C.POINTER(C.c_int32), _I64P, C.POINTER(C.c_uint64)]),
+    ("frisk_fasta_pack_2bit", C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I64P,
+                               C.POINTER(C.c_void_p), _I64P, C.POINTER(C.c_void_p), _I64P]),
     ("frisk_fasta_load_shard", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), _I64P, _I64P, _I64P]),
     ("frisk_fasta_load_shard_indexed", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,

@@ -107,13 +107,34 @@ inline bool for_lines(const char* base, size_t size, size_t b, size_t e, OnSeq&&
     return true;
 }
 
-inline bool parse_plain(const char* base, size_t size, Records& out, std::string& err, int max_threads = 32) {
+// The front half of reading a mapped plain file: the chunks the threads take (cut at line starts), what every chunk holds
+// (pass 1), the record table, and where every chunk's bases go - destinations are BYTE offsets into the staging layout
+// (records back to back, one PAD byte behind each) = padded positions of the resident batch.
+struct PlainPlan {
+    int T = 1;
+    std::vector<size_t> cut;                           // chunk t = file bytes [cut[t], cut[t + 1])
+    std::vector<int64_t> pre_dst;                      // destination of the chunk's leading bytes (-1: dropped, no record open)
+    std::vector<size_t> first_rec;                     // index of the first record that starts in the chunk
+    std::vector<int64_t> start;                        // destination of record r's first base; start[n] = total
+};
+
+template <class Fn>
+inline void run_threads(int T, Fn&& fn) {
+    if (T == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
+    for (auto& x : th) x.join();
+}
+
+inline bool plan_plain(const char* base, size_t size, Records& out, PlainPlan& pl, std::string& err, int max_threads = 32) {
     unsigned hw = std::thread::hardware_concurrency();
     int T = int(hw ? hw : 1);
     if (T > 32) T = 32;
     if (T > max_threads) T = max_threads < 1 ? 1 : max_threads;      // (N ranks of one node parse the same file at the same time)
     if (size < (size_t(1) << 24)) T = 1;
-    std::vector<size_t> cut(size_t(T) + 1, size);
+    pl.T = T;
+    std::vector<size_t>& cut = pl.cut;
+    cut.assign(size_t(T) + 1, size);
     cut[0] = 0;
     for (int t = 1; t < T; ++t) {                      // chunk t starts at the first line start at or after t * size / T
         size_t p = size * size_t(t) / size_t(T);
@@ -128,17 +149,13 @@ inline bool parse_plain(const char* base, size_t size, Records& out, std::string
                            [&](const char* b, const char* e) { if (c.bytes.empty()) c.pre += e - b; else c.bytes.back() += e - b; },
                            [&](const std::string& nm) { c.names.push_back(nm); c.bytes.push_back(0); });
     };
-    auto run = [&](auto&& fn) {
-        if (T == 1) { fn(0); return; }
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
-        for (auto& x : th) x.join();
-    };
-    run(pass1);
+    run_threads(T, pass1);
     for (auto& c : cc) if (c.bad) { err = "FASTA header without a name"; return false; }
     // sequential prefix: record lengths, and where every chunk's pieces go
-    std::vector<int64_t> pre_dst(size_t(T), -1);       // destination of the chunk's leading bytes (-1: dropped, no record open)
-    std::vector<size_t> first_rec(size_t(T), 0);       // index of the first record that starts in the chunk
+    std::vector<int64_t>& pre_dst = pl.pre_dst;
+    std::vector<size_t>& first_rec = pl.first_rec;
+    pre_dst.assign(size_t(T), -1);
+    first_rec.assign(size_t(T), 0);
     bool open = false;
     for (int t = 0; t < T; ++t) {
         ChunkCount& c = cc[size_t(t)];
@@ -151,33 +168,43 @@ inline bool parse_plain(const char* base, size_t size, Records& out, std::string
         }
     }
     if (out.lens.size() > size_t(0x7FFFFFFF)) { err = "too many FASTA records"; return false; }
-    std::vector<int64_t> start(out.lens.size() + 1, 0);
+    std::vector<int64_t>& start = pl.start;
+    start.assign(out.lens.size() + 1, 0);
     for (size_t r = 0; r < out.lens.size(); ++r) start[r + 1] = start[r] + out.lens[r] + 1;
+    // leading bytes of chunk t continue the record that was open when the chunk began: behind what earlier chunks gave it
+    std::vector<int64_t> filled(out.lens.size(), 0);
+    for (int t = 0; t < T; ++t) {
+        ChunkCount& c = cc[size_t(t)];
+        if (pre_dst[size_t(t)] == -2) {
+            const size_t r = first_rec[size_t(t)] - 1;
+            pre_dst[size_t(t)] = start[r] + filled[r];
+            filled[r] += c.pre;
+        }
+        for (size_t k = 0; k < c.names.size(); ++k) filled[first_rec[size_t(t)] + k] += c.bytes[k];
+    }
+    return true;
+}
+
+// pass 2 of chunk t: every sequence line's stripped text with its destination, in file order: on_piece(destination, bytes, n)
+template <class OnPiece>
+inline void walk_plain(const char* base, size_t size, const PlainPlan& pl, int t, OnPiece&& on_piece) {
+    int64_t dst = pl.pre_dst[size_t(t)];               // (< 0: text before the first header - dropped, L158-160)
+    size_t rec = pl.first_rec[size_t(t)];
+    for_lines(base, size, pl.cut[size_t(t)], pl.cut[size_t(t) + 1],
+              [&](const char* b, const char* e) { if (dst >= 0) { on_piece(dst, b, size_t(e - b)); dst += e - b; } },
+              [&](const std::string&) { dst = pl.start[rec]; ++rec; });
+}
+
+inline bool parse_plain(const char* base, size_t size, Records& out, std::string& err, int max_threads = 32) {
+    PlainPlan pl;
+    if (!plan_plain(base, size, out, pl, err, max_threads)) return false;
+    const std::vector<int64_t>& start = pl.start;
     out.stage.reserve(size_t(start[out.lens.size()]) + 64);          // (room for the caller's padding to a multiple of 32: no reallocation later)
     out.stage.resize(size_t(start[out.lens.size()]));
-    // leading bytes of chunk t continue the record that was open when the chunk began: behind what earlier chunks gave it
-    {
-        std::vector<int64_t> filled(out.lens.size(), 0);
-        for (int t = 0; t < T; ++t) {
-            ChunkCount& c = cc[size_t(t)];
-            if (pre_dst[size_t(t)] == -2) {
-                const size_t r = first_rec[size_t(t)] - 1;
-                pre_dst[size_t(t)] = start[r] + filled[r];
-                filled[r] += c.pre;
-            }
-            for (size_t k = 0; k < c.names.size(); ++k) filled[first_rec[size_t(t)] + k] += c.bytes[k];
-        }
-    }
-    auto pass2 = [&](int t) {
-        const ChunkCount& c = cc[size_t(t)];
-        uint8_t* dst = pre_dst[size_t(t)] >= 0 ? out.stage.data() + pre_dst[size_t(t)] : nullptr;
-        size_t rec = first_rec[size_t(t)];
-        for_lines(base, size, cut[size_t(t)], cut[size_t(t) + 1],
-                  [&](const char* b, const char* e) { if (dst) { std::memcpy(dst, b, size_t(e - b)); dst += e - b; } },
-                  [&](const std::string&) { dst = out.stage.data() + start[rec]; ++rec; });
-        (void)c;
-    };
-    run(pass2);
+    uint8_t* const stage = out.stage.data();
+    run_threads(pl.T, [&](int t) {
+        walk_plain(base, size, pl, t, [&](int64_t dst, const char* b, size_t n) { std::memcpy(stage + dst, b, n); });
+    });
     for (size_t r = 0; r < out.lens.size(); ++r) out.stage[size_t(start[r] + out.lens[r])] = 0;      // PAD behind every record
     return true;
 }

@@ -26,6 +26,7 @@
 #include "table_text.h"
 #include "fasta_index.h"
 #include "fasta_reader.h"
+#include "fasta_pack2.h"
 #include "seq_pack2.h"
 #include "hmm_host.h"
 
@@ -655,7 +656,14 @@ int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t
 #ifdef FRISK_TUNE
     const auto tt0 = std::chrono::steady_clock::now();
 #endif
-    if (!frisk_fasta::parse(path, rec, err)) return fail(c, FRISK_E_ARG, err);
+    // Read and packed on the HOST, by the reader's threads, straight into the 0.25 B/base form (fasta_pack2.h: no one-byte-per-base
+    // buffer in between; seq_pack2.h: 2-bit codes + run lists of the two masks).  PCIe then carries a quarter of the bytes (3.3 GB
+    // of ASCII -> 0.82 GB for a GRCh38-sized assembly), and the host copy stays until the next load: the CLI's sequence cache is
+    // written from it without touching the device.
+    const unsigned hw = std::thread::hardware_concurrency();
+    frisk_fasta::CodeVec packed;
+    frisk_pack2::Runs packed_runs;
+    if (!frisk_fasta::parse_pack(path, rec, packed, packed_runs, err, int(std::min(32u, hw ? hw : 1u)))) return fail(c, FRISK_E_ARG, err);
 #ifdef FRISK_TUNE
     const auto tt1 = std::chrono::steady_clock::now();
 #endif
@@ -664,13 +672,9 @@ int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t
     if (rc) return rc;
     frisk_ctx::Batch& B = c->b();
     B.seq_name = rec.names;
-    // Packed on the HOST, by the reader's threads, into the 0.25 B/base form (seq_pack2.h): 2-bit codes + run lists of the two
-    // masks.  PCIe then carries a quarter of the bytes (3.3 GB of ASCII -> 0.82 GB for a GRCh38-sized assembly), and the host
-    // copy stays until the next load: the CLI's sequence cache is written from it without touching the device.
-    const unsigned hw = std::thread::hardware_concurrency();
-    B.h_codes.resize(size_t(B.padded_len / 32) * 2);
-    frisk_pack2::pack_stage(rec.stage.data(), rec.lens.data(), int32_t(rec.lens.size()), B.h_codes.data(), B.h_runs,
-                            int(std::min(32u, hw ? hw : 1u)));
+    if (packed.size() != size_t(B.padded_len / 32) * 2) return fail(c, FRISK_E_STATE, "frisk_fasta_load: packed length and batch layout disagree");
+    B.h_codes.swap(packed);
+    B.h_runs = std::move(packed_runs);
     B.have_host2 = true;
 #ifdef FRISK_TUNE
     const auto tt2 = std::chrono::steady_clock::now();
@@ -690,13 +694,39 @@ int frisk_fasta_load(frisk_ctx* c, const char* path, int32_t* n_seq_out, int64_t
     {
         const auto tt3 = std::chrono::steady_clock::now();
         auto msf = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        if (std::getenv("FRISK_LOAD_SPLIT")) std::fprintf(stderr, "[load] parse %.1f ms, host pack %.1f ms, upload %.1f ms\n", msf(tt0, tt1), msf(tt1, tt2), msf(tt2, tt3));
+        if (std::getenv("FRISK_LOAD_SPLIT")) std::fprintf(stderr, "[load] read + pack %.1f ms, layout %.1f ms, upload %.1f ms\n", msf(tt0, tt1), msf(tt1, tt2), msf(tt2, tt3));
     }
 #endif
     int64_t total = 0;
     for (int64_t v : rec.lens) total += v;
     if (n_seq_out) *n_seq_out = int32_t(rec.lens.size());
     if (total_len_out) *total_len_out = total;
+    return FRISK_OK;
+}
+
+int frisk_fasta_pack_2bit(const char* path, int32_t* n_seq, int64_t** lens, uint32_t** codes, int64_t* n_code_words, int64_t** inv_runs,
+                          int64_t* n_inv, int64_t** low_runs, int64_t* n_low) {
+    if (!path || !n_seq || !lens || !codes || !n_code_words || !inv_runs || !n_inv || !low_runs || !n_low) return FRISK_E_ARG;
+    frisk_fasta::Records rec;
+    frisk_fasta::CodeVec packed;
+    frisk_pack2::Runs R;
+    std::string err;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (!frisk_fasta::parse_pack(path, rec, packed, R, err, int(std::min(32u, hw ? hw : 1u)))) return FRISK_E_ARG;
+    auto give = [](const void* src, size_t bytes, void** out) -> bool {
+        *out = std::malloc(std::max<size_t>(bytes, 16));
+        if (!*out) return false;
+        if (bytes) std::memcpy(*out, src, bytes);
+        return true;
+    };
+    void *pl = nullptr, *pc = nullptr, *pi = nullptr, *pw = nullptr;
+    const bool ok = give(rec.lens.data(), rec.lens.size() * 8, &pl) && give(packed.data(), packed.size() * 4, &pc) &&
+                    give(R.inv.data(), R.inv.size() * 8, &pi) && give(R.low.data(), R.low.size() * 8, &pw);
+    if (!ok) { std::free(pl); std::free(pc); std::free(pi); std::free(pw); return FRISK_E_HIP; }
+    *n_seq = int32_t(rec.lens.size());
+    *lens = static_cast<int64_t*>(pl); *codes = static_cast<uint32_t*>(pc); *n_code_words = int64_t(packed.size());
+    *inv_runs = static_cast<int64_t*>(pi); *n_inv = int64_t(R.inv.size() / 2);
+    *low_runs = static_cast<int64_t*>(pw); *n_low = int64_t(R.low.size() / 2);
     return FRISK_OK;
 }
 

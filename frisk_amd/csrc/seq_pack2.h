@@ -139,7 +139,9 @@ inline int64_t pack64_avx512(const uint8_t*&, int64_t p, int64_t, uint32_t*, int
 // big-endian in the word; the caller zeroed them), runs appended.  Words shared by two pieces are written by ONE thread only
 // because the threads' ranges are cut at multiples of 32.  Whole 16-position words go eight letters at a time (classify8);
 // sixty-four where the host has AVX-512, `wide`), the ragged head and tail of a piece letter by letter.
-inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* codes, Runs& out, bool wide = true) {
+// (shared_edges: the piece's first and last code word may be shared with a piece that ANOTHER thread packs at the same time - they
+//  are OR-ed in atomically; every word in between belongs to this piece alone)
+inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* codes, Runs& out, bool wide = true, bool shared_edges = false) {
     const uint8_t* T = lut().t;
     int64_t inv_b = -1, low_b = -1;
     int64_t p = p0;
@@ -156,7 +158,8 @@ inline void pack_piece(const uint8_t* src, int64_t p0, int64_t p1, uint32_t* cod
                 if (v & 8u) { if (low_b < 0) low_b = p; }
                 else if (low_b >= 0) { push_run(out.low, low_b, p); low_b = -1; }
             }
-            codes[(p - 1) >> 4] |= word;
+            if (shared_edges) __atomic_fetch_or(&codes[(p - 1) >> 4], word, __ATOMIC_RELAXED);
+            else codes[(p - 1) >> 4] |= word;
         }
     };
     letters(std::min<int64_t>(p1, (p0 + 15) & ~int64_t(15)));              // up to the first word boundary
@@ -214,11 +217,11 @@ inline void pack_batch(const uint8_t* const* seqs, const int64_t* lens, int32_t 
 }
 
 // The same from the parser's buffer (fasta_reader.h: records back to back, one PAD byte behind each): one source pointer.
-inline void pack_stage(const uint8_t* stage, const int64_t* lens, int32_t n_seq, uint32_t* codes, Runs& out, int threads) {
+inline void pack_stage(const uint8_t* stage, const int64_t* lens, int32_t n_seq, uint32_t* codes, Runs& out, int threads, bool wide = true) {
     std::vector<const uint8_t*> ptr(size_t(std::max(n_seq, 1)));
     int64_t pos = 0;
     for (int32_t s = 0; s < n_seq; ++s) { ptr[size_t(s)] = stage + pos; pos += lens[s] + 1; }
-    pack_batch(ptr.data(), lens, n_seq, codes, out, threads);
+    pack_batch(ptr.data(), lens, n_seq, codes, out, threads, wide);
 }
 
 // Runs of set bits of a bitmap over positions [0, P) (big-endian in the word), with the PAD positions - behind every

@@ -65,6 +65,28 @@ def pack_2bit_host(seqs):
     return codes, runs[0], runs[1], lens
 
 
+def fasta_pack_2bit_host(path):
+    """frisk_fasta_pack_2bit (host-only): a FASTA file straight into the 0.25 B/base form: (codes, inv_runs, low_runs, lens)."""
+    lib = _ffi.lib()
+    n = C.c_int32()
+    pl, pc, pi, pw = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nc, ni, nw = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = lib.frisk_fasta_pack_2bit(os.fsencode(path), C.byref(n), C.byref(pl), C.byref(pc), C.byref(nc), C.byref(pi), C.byref(ni),
+                                   C.byref(pw), C.byref(nw))
+    if rc != _ffi.OK:
+        raise _ffi.FriskHipError(rc, "frisk_fasta_pack_2bit failed: %s" % path)
+
+    def take(ptr, count, ctype, dtype):
+        a = np.frombuffer((ctype * count).from_address(ptr.value), dtype=dtype).copy() if count else np.empty(0, dtype)
+        lib.frisk_free(ptr)
+        return a
+    lens = [int(x) for x in take(pl, int(n.value), C.c_int64, np.int64)]
+    codes = take(pc, int(nc.value), C.c_uint32, np.uint32)
+    inv = take(pi, 2 * int(ni.value), C.c_int64, np.int64).reshape(-1, 2)
+    low = take(pw, 2 * int(nw.value), C.c_int64, np.int64).reshape(-1, 2)
+    return codes, inv, low, lens
+
+
 class Engine:
     def __init__(self, kmin, kmax, device=0):
         self._lib = _ffi.lib()

@@ -124,6 +124,11 @@ int frisk_fasta_load(frisk_ctx* ctx, const char* path, int32_t* n_seq, int64_t* 
 /* Host-only test utility: parse `path` with the native reader and return the number of records, their total length and an
  * FNV-1a digest over (name, 0, sequence, 0) of every record - what the CPU test-suite compares with the Python reader. */
 int frisk_fasta_digest(const char* path, int32_t* n_seq, int64_t* total_len, uint64_t* digest);
+/* Host-only: a FASTA file (plain or gzip) straight into the 0.25 B/base form - what frisk_fasta_load does before its upload (iterFasta
+ * L139-164 -> frisk_pack_2bit in one pass over the mapped file, no one-byte-per-base buffer in between).  All five arrays are
+ * malloc'd by the library (frisk_free): *lens (n_seq values), *codes (*n_code_words = 2 * P / 32 words), the two run lists. */
+int frisk_fasta_pack_2bit(const char* path, int32_t* n_seq, int64_t** lens, uint32_t** codes, int64_t* n_code_words, int64_t** inv_runs,
+                          int64_t* n_inv, int64_t** low_runs, int64_t* n_low);
 
 /* Multi-GPU form of frisk_fasta_load (window-tile sharding with halo): every rank parses the file, but keeps
  * resident only what it needs for ITS share of the job - the candidate windows [*cand_begin, *cand_end) of the job's

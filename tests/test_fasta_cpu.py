@@ -33,6 +33,13 @@ def _check(path):
     assert rc == 0
     assert n == len(names) and total == sum(len(s) for s in seqs)
     assert dig == _fnv(names, seqs)
+    # ... and the file straight into the 0.25 B/base form (frisk_fasta_pack_2bit: what frisk_fasta_load uploads - no staging buffer
+    # for plain files) against the Python reader's records through the packer of byte strings
+    from frisk_amd.engine import fasta_pack_2bit_host, pack_2bit_host
+    codes, inv, low, lens = fasta_pack_2bit_host(str(path))
+    wc, wi, wl, wlens = pack_2bit_host([s.encode("latin1") if isinstance(s, str) else s for s in seqs])
+    assert lens == wlens
+    assert np.array_equal(codes, wc) and np.array_equal(inv, wi) and np.array_equal(low, wl)
 
 
 def test_tricky_small_files(tmp_path):
@@ -96,6 +103,11 @@ def test_large_record_buffer_paths(tmp_path):
     a, b = _native(path), _native(gz)
     assert a[0] == 0 and a[1] == 2 and a[2] == 70_000_008
     assert a == b
+    from frisk_amd.engine import fasta_pack_2bit_host, pack_2bit_host
+    want = pack_2bit_host([big, b"ACGTACGT"])
+    for src in (path, gz):                                               # fused reader (plain) and staged reader (gzip): same form
+        got = fasta_pack_2bit_host(str(src))
+        assert got[3] == want[3] and all(np.array_equal(x, y) for x, y in zip(got[:3], want[:3]))
 
 
 def test_packed_sequence_cache_file_roundtrip(tmp_path):

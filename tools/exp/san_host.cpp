@@ -9,6 +9,7 @@
 #include "seq_pack2.h"
 #include "hmm_host.h"
 #include "fasta_index.h"
+#include "fasta_pack2.h"
 #include <fstream>
 #include <unistd.h>
 
@@ -87,7 +88,25 @@ int main() {
             "", ">only_header", ">a\nACGT\n>b\n\n>c\nAC\nGT", ">a desc\r\nACGT\r\nAC\r\n>b\r\nTT\r\n", "ACGT\n>late\nAAA\n", ">x\nACGTACGT\nACGTACGT\nAC\n>y\nAAAA\nAAAA\nAAAA",
             ">r\nACGT\nACG\nACGT\n", ">b\nAC GT\n\nAC\n", ">t\n" + std::string(200000, 'G') + "\n>u\n" + std::string(77, 'a'), "\n\n>z\nNNNN\n\n", ">\nAC\n>",
             ">w\nACGTAC\nACGTAC\nACGTAC\n\n>v\nAC\n"};
-        for (const std::string& text : files) {
+        std::vector<std::string> all(files);
+        for (int big = 0; big < 2; ++big) {             // > 16 MB: the readers' multi-threaded path, runs across lines, blocks and chunk cuts
+            std::string t;
+            const char letters[] = "ACGTACGTACGTacgtN";
+            while (t.size() < (size_t(20) << 20)) {
+                t += ">rec" + std::to_string(t.size()) + " x\n";
+                size_t n = (rng() % 7 == 0) ? rng() % 50 : rng() % 3000000;
+                const size_t width = big ? 61 : 60;
+                std::string q(n, 'A');
+                for (auto& ch : q) ch = letters[rng() % (sizeof(letters) - 1)];
+                for (int k = 0; k < 6 && n > 5000; ++k) {
+                    const size_t a = rng() % (n - 4000), ln = rng() % 4000;
+                    for (size_t i = a; i < a + ln; ++i) q[i] = (k & 1) ? 'N' : char(q[i] | 0x20);
+                }
+                for (size_t i = 0; i < n; i += width) { t.append(q, i, std::min(width, n - i)); t += big ? "\r\n" : "\n"; }
+            }
+            all.push_back(t);
+        }
+        for (const std::string& text : all) {
             { std::ofstream fh(path, std::ios::binary); fh << text; }
             frisk_fasta::Records rec;
             std::string err;
@@ -96,6 +115,22 @@ int main() {
             int64_t total = 0;
             for (int64_t n : rec.lens) total += n + 1;
             CHECK(int64_t(rec.stage.size()) >= total && rec.names.size() == rec.lens.size());
+            {   // the fused reader (no staging buffer) against parse() + pack_stage(), both letter widths
+                for (int wide = 0; wide < 2; ++wide) {
+                    frisk_fasta::Records r2;
+                    frisk_fasta::CodeVec c2;
+                    frisk_pack2::Runs R2;
+                    bool fused = false;
+                    CHECK(frisk_fasta::parse_pack(path.c_str(), r2, c2, R2, err, 1 + int(rng() % 5), &fused, wide != 0));
+                    CHECK(r2.names == rec.names && r2.lens == rec.lens);
+                    const int64_t P = frisk_pack2::padded_len(rec.lens.data(), int32_t(rec.lens.size()));
+                    std::vector<uint32_t> c1(size_t(P / 16));
+                    frisk_pack2::Runs R1;
+                    frisk_pack2::pack_stage(rec.stage.data(), rec.lens.data(), int32_t(rec.lens.size()), c1.data(), R1, 3, false);
+                    CHECK(c2.size() == c1.size() && std::equal(c1.begin(), c1.end(), c2.begin()));
+                    CHECK(R1.inv == R2.inv && R1.low == R2.low);
+                }
+            }
             frisk_fasta::MappedFile f(path.c_str());
             std::vector<frisk_fasta::FaiEntry> idx;
             std::string why;
