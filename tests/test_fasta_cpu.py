@@ -158,3 +158,14 @@ def test_packed_sequence_cache_file_roundtrip(tmp_path):
     with open(cache, "wb") as fh:
         fh.write(b"FRISK2B1" + np.uint64(2).tobytes() + json.dumps({}).encode())
     assert readSeqCache(cache, str(fa)) is None
+
+
+def test_random_awkward_files_fused_and_staged_readers():
+    """tools/exp/fuzz_fasta.py's generator, 120 seeds: random line widths inside a record, LF / CRLF mixes, blanks, stray text, empty
+    records, gzip every fifth - frisk_fasta_pack_2bit against the Python reader + frisk_pack_2bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_fasta.py"), "500", "120"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("done: 120 seeds, 0 bad"), (out.stdout[-1500:], out.stderr[-1500:])
