@@ -102,7 +102,7 @@ class ScoreTable:
                 "windowKLD": np.where(self.kld_is_int0 != 0, 0.0, self.kld), "GC": self.gc}
         if self.rip:
             data.update(PI=self.pi, SI=self.si, CRI=self.cri)
-        return pd.DataFrame(data, columns=self.columns)
+        return pd.DataFrame(data, columns=self.columns, copy=False)      # (views of the table's columns: nothing is written to them)
 
     # ------------------------------------------------------------------ text
     def text(self, fmt=None):
